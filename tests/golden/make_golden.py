@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures from the REAL reference (run in the build container only).
+
+Needs /root/reference and the in-place reference builds of oracle/Makefile
+(oracle/_ref/vfgs_ref, vfgs_ref_x, vfgs_trace).  Writes *data only*:
+
+  tests/golden/traces/<cfg>_<depth>_<fmt>.npz   what the reference firmware programs into the
+                                                hardware layer (setter calls + payloads) for
+                                                `vfgs -b <depth> -f <fmt> -r 12345 -c <cfg>`
+  tests/golden/md5.json                         md5 of the reference CLI's output on the LCG
+                                                synthetic input
+  tests/golden/frames/*.npz                     a few complete small reference outputs
+
+Nothing here is read at test time from /root/reference; the fixtures are.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import vfgs_testlib as T  # noqa: E402
+
+REF = Path("/root/reference")
+CFG = REF / "cfg"
+SEED = 12345
+SMALL = (192, 144, 3)  # width, height, frames
+
+FULL_SIZE = [  # BASELINE.json configs (name, w, h, depth, fmt, cfg, frames)
+    ("cfg1_1080p_10b_420_fgs_sei", 1920, 1080, 10, "420", "fgs_sei", 10),
+    ("cfg2_1080p_10b_420_ff_test1", 1920, 1080, 10, "420", "fgs_sei_ff_test1", 10),
+    ("cfg3_2160p_10b_420_ar_test1", 3840, 2160, 10, "420", "fgs_sei_ar_test1", 2),
+    ("cfg4_2160p_8b_444_afgs1_test1", 3840, 2160, 8, "444", "fgs_afgs1_test1", 2),
+    ("cfg5_4320p_10b_420_fgs_sei", 7680, 4320, 10, "420", "fgs_sei", 2),
+]
+
+NON_420 = [  # (cfg, depth, fmt): driven with --no-check (vfgs_main.c:235 rejects them otherwise)
+    ("fgs_afgs1_test1", 8, "444"), ("fgs_afgs1_test1", 10, "444"),
+    ("fgs_sei", 10, "444"), ("fgs_sei", 10, "422"), ("fgs_sei", 8, "422"),
+    ("fgs_sei_ff_test6", 10, "444"), ("fgs_sei_ff_test6", 8, "422"),
+    ("fgs_afgs1_test3", 10, "422"),
+]
+
+SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1)}
+
+
+def write_input(path, w, h, depth, fmt, nframes):
+    sx, sy = SUB[fmt]
+    frames, _ = T.lcg_frames(w, h, depth, sx, sy, nframes)
+    with open(path, "wb") as f:
+        for fr in frames:
+            f.write(fr.picture_bytes())
+
+
+def run_ref(w, h, depth, fmt, cfg, nframes, inp, out):
+    exe = "vfgs_ref" if fmt == "420" else "vfgs_ref_x"
+    cmd = [str(T.REF_DIR / exe), "-w", str(w), "-h", str(h), "-b", str(depth), "-f", fmt,
+           "-n", str(nframes), "-r", str(SEED)]
+    if fmt != "420":
+        cmd.append("--no-check")
+    if cfg:
+        cmd += ["-c", str(CFG / f"{cfg}.cfg")]
+    cmd += [inp, out]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+    return hashlib.md5(Path(out).read_bytes()).hexdigest()
+
+
+def record_trace(depth, fmt, cfg, dst):
+    with tempfile.NamedTemporaryFile(suffix=".trace", delete=False) as t:
+        tname = t.name
+    cmd = [str(T.REF_DIR / "vfgs_trace"), "--program-only", "--no-check", "-b", str(depth), "-f", fmt, "-r", str(SEED)]
+    if fmt == "420":
+        cmd.remove("--no-check")
+    if cfg:
+        cmd += ["-c", str(CFG / f"{cfg}.cfg")]
+    env = dict(os.environ, VFGS_TRACE_OUT=tname)
+    subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    T.save_trace_npz(T.parse_trace_file(tname), dst)
+    os.unlink(tname)
+
+
+def main():
+    T.build_oracle()
+    (T.GOLDEN / "traces").mkdir(parents=True, exist_ok=True)
+    (T.GOLDEN / "frames").mkdir(parents=True, exist_ok=True)
+    cfgs = sorted(p.stem for p in CFG.glob("*.cfg"))
+    md5 = {"seed": SEED, "lcg_seed": 1, "small": {}, "inputs": {}, "full": {}}
+    w, h, n = SMALL
+
+    with tempfile.TemporaryDirectory() as tmp:
+        inputs = {}
+        for depth in (8, 10):
+            for fmt in SUB:
+                p = f"{tmp}/in_{depth}_{fmt}.yuv"
+                write_input(p, w, h, depth, fmt, n)
+                inputs[(depth, fmt)] = p
+                md5["inputs"][f"{w}x{h}_{depth}_{fmt}_x{n}"] = hashlib.md5(Path(p).read_bytes()).hexdigest()
+
+        jobs = [(c, d, "420") for c in [None] + cfgs for d in (8, 10)] + NON_420
+        for cfg, depth, fmt in jobs:
+            name = f"{cfg or 'default'}_{depth}_{fmt}"
+            record_trace(depth, fmt, cfg, T.TRACES / f"{name}.npz")
+            out = f"{tmp}/out.yuv"
+            md5["small"][name] = run_ref(w, h, depth, fmt, cfg, n, inputs[(depth, fmt)], out)
+            if name in ("fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_ff_test6_8_422"):
+                sx, sy = SUB[fmt]
+                raw = np.frombuffer(Path(out).read_bytes(), dtype=np.uint16 if depth > 8 else np.uint8)
+                per = w * h + 2 * (w // sx) * (h // sy)
+                np.savez_compressed(T.GOLDEN / "frames" / f"{name}_{w}x{h}.npz", out=raw[:per])  # first frame only
+            print(name, md5["small"][name], flush=True)
+
+        for name, fw, fh, depth, fmt, cfg, nf in FULL_SIZE:
+            inp, out = f"{tmp}/full_in.yuv", f"{tmp}/full_out.yuv"
+            write_input(inp, fw, fh, depth, fmt, nf)
+            md5["full"][name] = {
+                "width": fw, "height": fh, "depth": depth, "format": fmt, "cfg": cfg, "frames": nf,
+                "input_md5": hashlib.md5(Path(inp).read_bytes()).hexdigest(),
+                "output_md5": run_ref(fw, fh, depth, fmt, cfg, nf, inp, out),
+            }
+            print(name, md5["full"][name], flush=True)
+            os.unlink(inp)
+            os.unlink(out)
+
+    (T.GOLDEN / "md5.json").write_text(json.dumps(md5, indent=1, sort_keys=True) + "\n")
+
+
+if __name__ == "__main__":
+    main()

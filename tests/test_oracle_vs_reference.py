@@ -1,0 +1,114 @@
+"""CPU, build container only: the oracle against the REAL reference hardware layer
+(oracle/_ref/libvfgs_ref.so, compiled in place from /root/reference/src/vfgs_hw.c).
+
+Covers what the md5 fixtures cannot: padding bytes, ragged widths, garbage (out of
+range) samples, every chroma format, the seed registers after each call, and the
+line API called with arbitrary y.
+"""
+import numpy as np
+import pytest
+
+import vfgs_testlib as T
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(not T.have_reference(), reason="oracle/_ref not built (no /root/reference here)")]
+
+SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1)}
+
+
+def pair(name):
+    ref, ora = T.ReferenceHW(), T.OracleHW()
+    rec = T.load_trace(name)
+    T.replay(ref, rec)
+    T.replay(ora, rec)
+    return ref, ora, T.trace_geometry(rec)
+
+
+@pytest.mark.parametrize("name", T.list_traces())
+def test_every_cfg_full_buffer(name):
+    """All planes incl. stride padding, 2 frames, garbage in the padding, W%16 != 0."""
+    ref, ora, (depth, sx, sy) = pair(name)
+    frames, _ = T.lcg_frames(200, 150 if sy == 1 else 152, depth, sx, sy, 2, garbage_padding=True)
+    for f in frames:
+        a, b, c = f.copy(), f.copy(), f.copy()
+        ref.add_grain_frame(a)
+        ora.add_grain_frame(b)
+        assert a.equal_all(b)
+    # closed form on a fresh pair of contexts, frame by frame
+    ref2, ora2, _ = pair(name)
+    for f in frames:
+        a, c = f.copy(), f.copy()
+        ref2.add_grain_frame(a)
+        ora2.add_grain_frame(c, closed_form=True)
+        assert a.equal_all(c)
+
+
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_8_422"])
+def test_out_of_range_samples(name):
+    """10-bit containers holding up to 16-bit garbage: intensity wraps as a uint8 (quirk 8)."""
+    ref, ora, (depth, sx, sy) = pair(name)
+    f = T.Frame(256, 144, depth, sx, sy)
+    rng = np.random.default_rng(7)
+    for p in f.planes():
+        p[...] = rng.integers(0, 1 << (16 if depth > 8 else 8), p.shape).astype(f.dtype)
+    a, b, c = f.copy(), f.copy(), f.copy()
+    ref.add_grain_frame(a)
+    ora.add_grain_frame(b)
+    assert a.equal_all(b)
+    T.replay(ora, T.load_trace(name))  # re-seed
+    ora.add_grain_frame(c, closed_form=True)
+    assert a.equal_all(c)
+
+
+def test_seed_registers_track_reference_stream():
+    """After set_seed the four registers follow the closed-form offsets; checked through output
+    of a *following* frame with a different height (state carries across frames, quirk 4)."""
+    for closed in (False, True):
+        ref, ora, (depth, sx, sy) = pair("fgs_sei_10_420")
+        for (w, h) in ((192, 144), (320, 208), (192, 130)):
+            f, _ = T.lcg_frames(w, h, depth, sx, sy, 1, state=w)
+            a, b = f[0].copy(), f[0].copy()
+            ref.add_grain_frame(a)
+            ora.add_grain_frame(b, closed_form=closed)
+            assert a.equal_all(b), (closed, w, h)
+
+
+def test_line_api_arbitrary_y_order():
+    """Lines fed out of order / repeated: the seed state machine must match call for call."""
+    ref, ora, (depth, sx, sy) = pair("fgs_sei_10_420")
+    f, _ = T.lcg_frames(192, 144, depth, sx, sy, 1)
+    a, b = f[0].copy(), f[0].copy()
+    order = [0, 1, 16, 17, 5, 32, 32, 33, 48, 2, 64, 65, 80, 15, 16, 96]
+    for fr, hw in ((a, ref), (b, ora)):
+        for y in order:
+            hw.add_grain_line(fr.Y[y].ctypes.data, fr.U[y // 2].ctypes.data, fr.V[y // 2].ctypes.data, y, fr.width)
+    assert a.equal_all(b)
+
+
+def test_default_power_on_state():
+    """No programming at all: 0xdeadbeef seeds, zero banks/LUTs -> only the clip acts."""
+    ref, ora = T.ReferenceHW(), T.OracleHW()
+    for hw in (ref, ora):
+        hw.set_depth(10)
+    f, _ = T.lcg_frames(192, 144, 10, 2, 2, 1)
+    a, b = f[0].copy(), f[0].copy()
+    ref.add_grain_frame(a)
+    ora.add_grain_frame(b)
+    assert a.equal_all(b)
+    assert a.Y.max() <= 1020  # quirk 1: 255<<2
+
+
+def test_lfsr_stream_word_recurrence():
+    lib = T.oracle_lib()
+    for reg in (0xdeadbeef, 12345 << 1, 1 << 31, 0xFFFFFFFF, 2):
+        n = 4096
+        words = np.zeros(n, np.uint32)
+        lib.vfgs_oracle_lfsr_stream(reg, words.ctypes.data, n)
+        # bit-serial check of windows at many offsets
+        r = reg
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+        for target in range(0, 70000):
+            if target % 4999 == 0:
+                win = int(np.packbits(bits[target:target + 32], bitorder="little").view(np.uint32)[0])
+                assert win == r, (hex(reg), target)
+            r = lib.vfgs_oracle_lfsr_step(r)
