@@ -1,0 +1,123 @@
+/*
+ * libvfgs_hip -- MI355X (gfx950) film grain synthesis hardware layer.
+ *
+ * C ABI.  Two groups of entry points:
+ *
+ * (1) DROP-IN: the ten functions of the reference hardware-layer interface,
+ *     /root/reference/src/vfgs_hw.h:51-62, with identical names, argument
+ *     meaning and (absence of) error reporting, so that the reference's
+ *     vfgs_fw.c (callers: vfgs_fw.c:585,594,637,638,643,672-704) and
+ *     vfgs_main.c (callers: vfgs_main.c:674,750,751,760) link against this
+ *     library unchanged.  The reference header spells its types with macros
+ *     (`int8`, `uint8`, `uint32`, vfgs_hw.h:40-47); the plain C types below
+ *     are the same types.  State is a process-global singleton exactly like
+ *     the reference's file-scope statics (vfgs_hw.c:49-68); all pointer
+ *     arguments are borrowed for the duration of the call only.
+ *
+ * (2) EXTENSIONS (vfgs_add_grain_stripe, vfgs_hip_*): the throughput path.
+ *     The reference has no stripe/frame entry; these are defined here with
+ *     the contract "same samples and same seed registers afterwards as
+ *     calling vfgs_add_grain_line for every line of the stripe, in order".
+ *
+ * There is no CPU fallback: every processing call runs HIP kernels and fails
+ * loudly (message on stderr + abort for the void drop-in calls, nonzero return
+ * for the vfgs_hip_* calls) when no gfx950 device/runtime is usable.
+ */
+#ifndef VFGS_HIP_H
+#define VFGS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFGS_HIP_MAX_PATTERNS 8   /* vfgs_hw.h:49 */
+
+/* ---- (1) drop-in hardware-layer interface -------------------------------- */
+
+/* vfgs_hw.h:51 / vfgs_hw.c:314-318 -- P: 64x64 int8, row-major. index 0..7. */
+void vfgs_set_luma_pattern(int index, signed char* P);
+/* vfgs_hw.h:52 / vfgs_hw.c:320-325 -- copies 64/csuby rows of 64/csubx bytes, source
+ * pitch 64/csuby (sic): depends on the subsampling set EARLIER. index 0..7. */
+void vfgs_set_chroma_pattern(int index, signed char* P);
+/* vfgs_hw.h:53 / vfgs_hw.c:327-331 -- 256 scale factors for component c (0=Y,1=Cb,2=Cr). */
+void vfgs_set_scale_lut(int c, unsigned char lut[]);
+/* vfgs_hw.h:54 / vfgs_hw.c:333-337 -- 256 pattern selectors; slot = lut[i] >> 4 (must be <= 8). */
+void vfgs_set_pattern_lut(int c, unsigned char lut[]);
+/* vfgs_hw.h:56 / vfgs_hw.c:339-344 -- loads seed<<1 into all four LFSR registers. */
+void vfgs_set_seed(unsigned int seed);
+/* vfgs_hw.h:57 / vfgs_hw.c:346-350 -- shift in 2..7. */
+void vfgs_set_scale_shift(int shift);
+/* vfgs_hw.h:58 / vfgs_hw.c:352-362 -- 8 or 10. */
+void vfgs_set_depth(int depth);
+/* vfgs_hw.h:59 / vfgs_hw.c:364-380 */
+void vfgs_set_legal_range(int legal);
+/* vfgs_hw.h:60 / vfgs_hw.c:382-388 -- each 1 or 2. */
+void vfgs_set_chroma_subsampling(int subx, int suby);
+/* vfgs_hw.h:62 / vfgs_hw.c:288-312 -- Y/U/V: HOST pointers to the start of line y in each
+ * plane (U,V: chroma row y/csuby).  In place; complete when the call returns. */
+void vfgs_add_grain_line(void* Y, void* U, void* V, int y, int width);
+
+/* ---- (2) extensions ------------------------------------------------------- */
+
+/* Host-memory stripe: lines y .. y+height-1, strides in samples.  Equivalent to `height`
+ * consecutive vfgs_add_grain_line calls (one H2D + kernel + D2H instead of `height`). */
+void vfgs_add_grain_stripe(void* Y, void* U, void* V, unsigned y, unsigned width,
+                           unsigned height, unsigned stride, unsigned cstride);
+
+/* Select the HIP device (default: the current device at first use) and create the
+ * device-side state.  Returns 0 on success. */
+int vfgs_hip_init(int device);
+void vfgs_hip_shutdown(void);
+
+/* Back to the reference's power-on state (vfgs_hw.c:49-63): zero banks and LUTs, seeds
+ * 0xdeadbeef, 8-bit, 4:2:0, full range.  The reference has no such call because its state
+ * only ever lives for one process; a long-lived library needs one. */
+void vfgs_hip_reset_state(void);
+
+/* Device-resident stripe / frame: dY/dU/dV are DEVICE pointers to the first line of the
+ * stripe (dU/dV: chroma row y/csuby); 16-byte aligned, pitch*bytes_per_sample % 16 == 0,
+ * stride >= 16*ceil(width/16) (the reference writes whole 16-sample blocks, SURVEY 8a
+ * quirk 7).  Asynchronous on `stream` (a hipStream_t, may be NULL).  Returns 0 on success. */
+int vfgs_hip_add_grain_stripe_dev(void* dY, void* dU, void* dV, unsigned y, unsigned width,
+                                  unsigned height, unsigned stride, unsigned cstride, void* stream);
+int vfgs_hip_add_grain_frame_dev(void* dY, void* dU, void* dV, unsigned width, unsigned height,
+                                 unsigned stride, unsigned cstride, void* stream);
+
+/* Multi-GPU stripe split (no collective): process only lines [part_y, part_y+part_height)
+ * of a frame of `frame_height` lines -- pointers address line part_y -- but advance the
+ * seed registers as if the whole frame had been processed, so that every rank stays in
+ * lock step.  part_y must be a multiple of 16. */
+int vfgs_hip_add_grain_frame_part_dev(void* dY, void* dU, void* dV, unsigned width,
+                                      unsigned frame_height, unsigned part_y, unsigned part_height,
+                                      unsigned stride, unsigned cstride, void* stream);
+
+/* Batch: `nframes` equally shaped device-resident frames in ONE launch, processed as
+ * consecutive frames (frame f+1 continues frame f's seed state).  Plane pointers of frame
+ * f are dY + f*y_frame_pitch_bytes etc. */
+int vfgs_hip_add_grain_frames_dev(void* dY, void* dU, void* dV, unsigned width, unsigned height,
+                                  unsigned stride, unsigned cstride, unsigned nframes,
+                                  uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes,
+                                  void* stream);
+
+/* {rnd, rnd_up, line_rnd, line_rnd_up} as the reference would hold them (vfgs_hw.c:52-55). */
+void vfgs_hip_get_seed_state(uint32_t out[4]);
+
+/* Last error of a vfgs_hip_* call (0 = none) and its text. */
+int vfgs_hip_last_error(void);
+const char* vfgs_hip_last_error_string(void);
+
+/* Timing helper for harnesses: average device time in microseconds of the grain kernels
+ * launched between begin/end on `stream` (hipEvent pair on that stream). */
+int vfgs_hip_timer_begin(void* stream);
+int vfgs_hip_timer_end(void* stream, float* elapsed_ms);
+
+/* Introspection for benchmarks/tests. */
+int vfgs_hip_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* name, int name_len);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* VFGS_HIP_H */

@@ -1,0 +1,189 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the oracle and the golden
+vectors of the real reference.  Bit-exact is the bar (integer path)."""
+import json
+
+import numpy as np
+import pytest
+
+import vfgs_testlib as T
+
+pytestmark = pytest.mark.gpu
+
+MD5 = json.loads((T.GOLDEN / "md5.json").read_text())
+SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1)}
+W, H, N = 192, 144, 3
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from versatilefilmgrain_amd import hw
+    h = hw.VfgsHip(device=0)
+    info = h.device_info()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    print(info)
+    return h
+
+
+def program(hip, name):
+    hip.lib.vfgs_hip_reset_state()
+    rec = T.load_trace(name)
+    T.replay(hip, rec)
+    ora = T.OracleHW()
+    T.replay(ora, rec)
+    return ora, T.trace_geometry(rec)
+
+
+def host_frame_call(hip, f):
+    hip.add_grain_stripe(f.Y.ctypes.data, f.U.ctypes.data, f.V.ctypes.data, 0, f.width, f.height, f.stride, f.cstride)
+
+
+@pytest.mark.parametrize("name", sorted(MD5["small"]))
+def test_small_frames_host_stripe_vs_golden_md5_and_oracle(hip, name):
+    """Every cfg x depth x format: 3 frames 192x144 through vfgs_add_grain_stripe (host memory)."""
+    ora, (depth, sx, sy) = program(hip, name)
+    frames, _ = T.lcg_frames(W, H, depth, sx, sy, N)
+    want = [f.copy() for f in frames]
+    for f, w in zip(frames, want):
+        host_frame_call(hip, f)
+        ora.add_grain_frame(w)
+        assert f.equal_all(w)
+        assert hip.seed_state() == ora.seed_state()
+    assert T.md5_frames(frames) == MD5["small"][name]
+
+
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_ff_test6_8_422", "fgs_sei_ar_test1_8_420"])
+def test_line_api_matches_oracle_line_by_line(hip, name):
+    """The drop-in entry point itself: one call per line, host pointers, in order."""
+    ora, (depth, sx, sy) = program(hip, name)
+    f, _ = T.lcg_frames(W, H, depth, sx, sy, 1)
+    a, b = f[0].copy(), f[0].copy()
+    for fr, hwimpl in ((a, hip), (b, ora)):
+        for y in range(fr.height):
+            hwimpl.add_grain_line(fr.Y[y].ctypes.data, fr.U[y // sy].ctypes.data, fr.V[y // sy].ctypes.data, y, fr.width)
+    assert a.equal_all(b)
+    assert hip.seed_state() == ora.seed_state()
+
+
+def test_line_api_arbitrary_order(hip):
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    f, _ = T.lcg_frames(W, H, depth, sx, sy, 1)
+    a, b = f[0].copy(), f[0].copy()
+    order = [0, 1, 16, 17, 5, 32, 32, 33, 48, 2, 64, 65, 80, 15, 16, 96]
+    for fr, hwimpl in ((a, hip), (b, ora)):
+        for y in order:
+            hwimpl.add_grain_line(fr.Y[y].ctypes.data, fr.U[y // 2].ctypes.data, fr.V[y // 2].ctypes.data, y, fr.width)
+    assert a.equal_all(b)
+    assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_sei_8_422", "fgs_afgs1_test1_10_444", "fgs_sei_ff_test6_10_444"])
+@pytest.mark.parametrize("width,height", [(200, 152), (136, 130), (1000, 160)])
+def test_ragged_sizes_garbage_padding_and_out_of_range(hip, name, width, height):
+    """W % 16 != 0 (whole last block is processed in the stride padding, quirk 7), stripes that
+    end mid block row, garbage everywhere incl. > 10-bit values (quirk 8)."""
+    ora, (depth, sx, sy) = program(hip, name)
+    f = T.Frame(width, height, depth, sx, sy)
+    rng = np.random.default_rng(width)
+    for p in f.planes():
+        p[...] = rng.integers(0, 1 << (16 if depth > 8 else 8), p.shape).astype(f.dtype)
+    a, b = f.copy(), f.copy()
+    host_frame_call(hip, a)
+    ora.add_grain_frame(b)
+    assert a.equal_all(b)
+
+
+def test_stripes_equal_whole_frame(hip):
+    """A frame fed as uneven host stripes (not multiples of 16) == line by line."""
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    f, _ = T.lcg_frames(320, 208, depth, sx, sy, 1)
+    a, b = f[0].copy(), f[0].copy()
+    y = 0
+    for h in (6, 26, 32, 1, 15, 64, 64):
+        hip.add_grain_stripe(a.Y[y].ctypes.data, a.U[y // 2].ctypes.data, a.V[y // 2].ctypes.data, y, a.width, h, a.stride, a.cstride)
+        y += h
+    assert y == 208
+    ora.add_grain_frame(b)
+    assert a.equal_all(b)
+    assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("key", sorted(MD5["full"]))
+def test_full_size_device_frames_md5(hip, key):
+    """BASELINE.json configs at full size, device-resident, vs the reference CLI's md5."""
+    from gpu_util import DevFrame, stream_ptr
+    g = MD5["full"][key]
+    sx, sy = SUB[g["format"]]
+    ora, _ = program(hip, f'{g["cfg"]}_{g["depth"]}_{g["format"]}')
+    frames, _ = T.lcg_frames(g["width"], g["height"], g["depth"], sx, sy, g["frames"])
+    assert T.md5_frames(frames) == g["input_md5"]
+    out = []
+    for f in frames:
+        d = DevFrame(f)
+        hip.add_grain_frame_dev(*d.ptrs(), f.width, f.height, f.stride, f.cstride, stream_ptr())
+        out.append(d.download())
+    assert T.md5_frames(out) == g["output_md5"]
+
+
+def test_batch_launch_equals_sequential(hip):
+    import torch
+    from gpu_util import stream_ptr
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    n, w, h = 5, 640, 368
+    frames, _ = T.lcg_frames(w, h, depth, sx, sy, n)
+    want = [f.copy() for f in frames]
+    for f in want:
+        ora.add_grain_frame(f)
+    f0 = frames[0]
+    Y = torch.from_numpy(np.stack([f.Y for f in frames]).view(np.uint8)).cuda()
+    U = torch.from_numpy(np.stack([f.U for f in frames]).view(np.uint8)).cuda()
+    V = torch.from_numpy(np.stack([f.V for f in frames]).view(np.uint8)).cuda()
+    hip.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, h, f0.stride, f0.cstride, n,
+                             Y[0].numel(), U[0].numel(), stream_ptr())
+    torch.cuda.synchronize()
+    for i, f in enumerate(want):
+        assert np.array_equal(Y[i].cpu().numpy().view(f.dtype).reshape(f.Y.shape), f.Y)
+        assert np.array_equal(U[i].cpu().numpy().view(f.dtype).reshape(f.U.shape), f.U)
+        assert np.array_equal(V[i].cpu().numpy().view(f.dtype).reshape(f.V.shape), f.V)
+    assert hip.seed_state() == ora.seed_state()
+
+
+def test_frame_parts_equal_whole_frame_and_keep_seeds(hip):
+    """The multi-GPU split on one GPU: 3 uneven 16-aligned parts, each by a freshly seeded
+    library state (as a separate rank would), assemble to the whole frame."""
+    from gpu_util import DevFrame, stream_ptr
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    f, _ = T.lcg_frames(640, 368, depth, sx, sy, 2)
+    want = [x.copy() for x in f]
+    for x in want:
+        ora.add_grain_frame(x)
+    parts = [(0, 128), (128, 112), (240, 128)]
+    devs = [DevFrame(x) for x in f]
+    for (py, ph) in parts:
+        program(hip, "fgs_sei_10_420")            # every "rank" starts from the same programmed state
+        for d, x in zip(devs, f):
+            hip.add_grain_frame_part_dev(*d.ptrs(py), x.width, x.height, py, ph, x.stride, x.cstride, stream_ptr())
+        assert hip.seed_state() == ora.seed_state()
+    for d, wnt in zip(devs, want):
+        assert d.download().equal_all(wnt)
+
+
+def test_zero_scale_is_clip_only_at_full_size(hip):
+    """Size-independent property on a 4320p frame: all-zero scale LUTs -> out = clip(in)
+    (quirk 1: 10-bit full range clips at 1020), and a second pass changes nothing."""
+    import torch
+    from gpu_util import stream_ptr
+    hip.lib.vfgs_hip_reset_state()
+    hip.set_depth(10)
+    w, h = 7680, 4320
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Y = torch.randint(0, 1024, (h, w), dtype=torch.int16, device="cuda", generator=g)
+    U = torch.randint(0, 1024, (h // 2, w // 2), dtype=torch.int16, device="cuda", generator=g)
+    V = torch.randint(0, 1024, (h // 2, w // 2), dtype=torch.int16, device="cuda", generator=g)
+    ref = [t.clamp(0, 1020).clone() for t in (Y, U, V)]
+    for _ in range(2):
+        hip.add_grain_frame_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, h, w, w // 2, stream_ptr())
+        torch.cuda.synchronize()
+        for a, b in zip((Y, U, V), ref):
+            assert torch.equal(a, b)

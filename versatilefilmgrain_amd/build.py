@@ -1,0 +1,56 @@
+"""Build libvfgs_hip.so (gfx950 only) in-tree with hipcc.
+
+The .so is git-ignored but travels to the GPU box with the snapshot; nothing is JIT-built
+at run time.  `python -m versatilefilmgrain_amd.build` or `__graft_entry__.build()`.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import tempfile
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libvfgs_hip.so"
+SOURCES = [CSRC / "vfgs_kernel.hip", CSRC / "vfgs_host.cpp"]
+HEADERS = [CSRC / "vfgs_layout.h", PKG.parent / "include" / "vfgs_hip.h"]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: libvfgs_hip.so can only be built with ROCm")
+    return exe
+
+
+def up_to_date() -> bool:
+    if not LIB.exists():
+        return False
+    t = LIB.stat().st_mtime
+    return all(p.stat().st_mtime <= t for p in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if up_to_date() and not force:
+        return LIB
+    with tempfile.TemporaryDirectory(prefix="vfgs_build_") as tmp:
+        out = Path(tmp) / LIB.name
+        cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function", "-o", str(out)] + [str(s) for s in SOURCES]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(r.stderr)
+        os.replace(out, LIB) if out.stat().st_dev == LIB.parent.stat().st_dev else shutil.copyfile(out, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,691 @@
+// Host side of libvfgs_hip: the process-global hardware-layer state of the reference
+// (vfgs_hw.c:49-63) kept on the host, its device images, the seed state machine
+// (vfgs_hw.c:288-298,309-310) expressed as positions in one LFSR bit stream, and the
+// C ABI of include/vfgs_hip.h.  All sample arithmetic happens in vfgs_kernel.hip; there is
+// no CPU implementation of the grain path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vfgs_hip.h"
+#include "vfgs_layout.h"
+
+namespace vfgs {
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, int grid, hipStream_t stream);
+int table_bytes(int csubx, int csuby);
+}
+
+namespace {
+
+using vfgs::KernelArgs;
+
+// ------------------------------------------------------------------------------------
+// errors
+
+int g_err = 0;
+std::string g_errstr;
+
+int fail(int code, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_err = code;
+	g_errstr = buf;
+	return code;
+}
+
+[[noreturn]] void die(const char* what)
+{
+	// the drop-in calls return void (vfgs_hw.h:51-62): like the reference's asserts, abort
+	fprintf(stderr, "libvfgs_hip: fatal: %s (%s)\n", what, g_errstr.c_str());
+	abort();
+}
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t e_ = (expr);                                                                \
+		if (e_ != hipSuccess)                                                                  \
+			return fail((int)e_, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+// ------------------------------------------------------------------------------------
+// LFSR bit stream (vfgs_hw.c:74-79 as a random-access sequence)
+//
+// t[0..31] are the bits of the register, t[m] = t[m-31] ^ t[m-3] for m >= 32; the register
+// after n steps is the window t[n..n+31].  Raising the characteristic polynomial to the
+// 32nd power over GF(2) gives the same recurrence on whole 32-bit words,
+// W[n] = W[n-31] ^ W[n-3], valid from word 32 on (every referenced bit index >= 1), so a
+// megabyte of stream costs a few hundred microseconds on the host.
+
+uint32_t lfsr_step(uint32_t r)
+{
+	return (r >> 1) | ((((r >> 1) ^ (r >> 29)) & 1u) << 31);
+}
+
+// Host + device image of a window of the stream, in a small ring of slots (pinned host
+// words + device words) so that a refill never overwrites what queued kernels still read.
+class StreamCache {
+public:
+	static constexpr int kSlots = 4;
+	static constexpr uint64_t kMinWords = 1u << 18;  // 1 MiB of stream per refill = 64 frames of 4320p
+
+	void reseed(uint32_t reg)
+	{
+		seed_reg_ = reg;
+		ck_word_ = 0;
+		ck_reg_ = reg;
+		cur_ = -1;   // nothing valid; slots keep their allocations
+	}
+
+	// register after `bit` steps
+	uint32_t window(uint64_t bit)
+	{
+		const uint64_t w = bit >> 5;
+		const unsigned sh = bit & 31;
+		if (cur_ >= 0 && w >= slot_[cur_].wbase && w + 1 < slot_[cur_].wbase + slot_[cur_].nwords)
+		{
+			const uint32_t* p = slot_[cur_].host + (w - slot_[cur_].wbase);
+			return sh ? (p[0] >> sh) | (p[1] << (32 - sh)) : p[0];
+		}
+		uint64_t from = 0;
+		uint32_t reg = seed_reg_;
+		if (w >= ck_word_) { from = ck_word_; reg = ck_reg_; }
+		for (uint64_t n = (bit - (from << 5)); n; n--) reg = lfsr_step(reg);
+		return reg;
+	}
+
+	// make the device image cover absolute bits [lo, hi + 64); returns 0 or a HIP error
+	hipError_t ensure(uint64_t lo, uint64_t hi, hipStream_t stream)
+	{
+		const uint64_t wlo = lo >> 5, whi = (hi >> 5) + 4;
+		if (cur_ >= 0 && wlo >= slot_[cur_].wbase && whi <= slot_[cur_].wbase + slot_[cur_].nwords)
+			return hipSuccess;
+		const uint32_t reg0 = window(wlo << 5);
+		const uint64_t n = std::max<uint64_t>(kMinWords, 2 * (whi - wlo));
+		const int nxt = (cur_ < 0 ? last_ + 1 : cur_ + 1) % kSlots;
+		Slot& s = slot_[nxt];
+		hipError_t e;
+		if (s.ev && (e = hipEventSynchronize(s.ev)) != hipSuccess) return e;   // normally long complete
+		if (s.cap < n)
+		{
+			if (s.host) (void)hipHostFree(s.host);
+			if (s.dev) (void)hipFree(s.dev);
+			s.host = nullptr; s.dev = nullptr; s.cap = 0;
+			if ((e = hipHostMalloc((void**)&s.host, n * 4, hipHostMallocDefault)) != hipSuccess) return e;
+			if ((e = hipMalloc((void**)&s.dev, n * 4)) != hipSuccess) return e;
+			s.cap = n;
+		}
+		if (!s.ev && (e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)) != hipSuccess) return e;
+		// 32 words bit by bit, then W[n] = W[n-31] ^ W[n-3] (valid from word 32 of any base)
+		uint32_t reg = reg0;
+		uint64_t i = 0;
+		for (; i < n && i < 32; i++)
+		{
+			s.host[i] = reg;
+			for (int k = 0; k < 32; k++) reg = lfsr_step(reg);
+		}
+		for (; i < n; i++) s.host[i] = s.host[i - 31] ^ s.host[i - 3];
+		s.wbase = wlo;
+		s.nwords = n;
+		if ((e = hipMemcpyAsync(s.dev, s.host, n * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+		// the slot we are leaving: remember when its last reader (queued before now) is done
+		if (cur_ >= 0 && slot_[cur_].ev) (void)hipEventRecord(slot_[cur_].ev, stream);
+		cur_ = last_ = nxt;
+		ck_word_ = wlo;
+		ck_reg_ = reg0;
+		return hipSuccess;
+	}
+
+	const uint32_t* dev() const { return cur_ < 0 ? nullptr : slot_[cur_].dev; }
+	uint64_t base_bit() const { return cur_ < 0 ? 0 : slot_[cur_].wbase << 5; }
+
+	void release()
+	{
+		for (Slot& s : slot_)
+		{
+			if (s.host) (void)hipHostFree(s.host);
+			if (s.dev) (void)hipFree(s.dev);
+			if (s.ev) (void)hipEventDestroy(s.ev);
+			s = Slot{};
+		}
+		cur_ = -1;
+	}
+
+private:
+	struct Slot {
+		uint32_t* host = nullptr;
+		uint32_t* dev = nullptr;
+		uint64_t cap = 0, wbase = 0, nwords = 0;
+		hipEvent_t ev = nullptr;
+	};
+	Slot slot_[kSlots];
+	int cur_ = -1, last_ = -1;
+	uint32_t seed_reg_ = 0xdeadbeefu;   // register at bit 0 (vfgs_hw.c:52-55 power-on value)
+	uint64_t ck_word_ = 0;              // a known (word, register) point to step from
+	uint32_t ck_reg_ = 0xdeadbeefu;
+};
+
+// ------------------------------------------------------------------------------------
+// device buffer ring: an image that is being replaced may still be read by kernels that
+// were queued earlier on another stream, so replacements go to the next slot.
+
+struct DevRing {
+	static constexpr int N = 4;
+	void* buf[N] = {nullptr, nullptr, nullptr, nullptr};
+	size_t cap[N] = {0, 0, 0, 0};
+	int cur = -1;
+
+	hipError_t next(size_t bytes, void** out)
+	{
+		cur = (cur + 1) % N;
+		if (cap[cur] < bytes)
+		{
+			if (buf[cur]) (void)hipFree(buf[cur]);
+			buf[cur] = nullptr;
+			cap[cur] = 0;
+			hipError_t e = hipMalloc(&buf[cur], bytes);
+			if (e != hipSuccess) return e;
+			cap[cur] = bytes;
+		}
+		*out = buf[cur];
+		return hipSuccess;
+	}
+	void* current() const { return cur < 0 ? nullptr : buf[cur]; }
+	void release()
+	{
+		for (int i = 0; i < N; i++) { if (buf[i]) (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+		cur = -1;
+	}
+};
+
+// ------------------------------------------------------------------------------------
+// the singleton
+
+struct State {
+	// mirror of the reference's statics (vfgs_hw.c:49-63)
+	int8_t bank[2][vfgs::kSlots + 1][64][64];
+	uint8_t slut[3][256];
+	uint8_t plut[3][256];
+	int scale_shift = 5 + 6;
+	int bs = 0;
+	int ymin = 0, ymax = 255, cmin = 0, cmax = 255;
+	int csubx = 2, csuby = 2;
+
+	// seed registers as positions in the stream: {rnd, rnd_up, line_rnd, line_rnd_up}
+	StreamCache lfsr;
+	uint64_t rnd = 0, rnd_up = 0, line_rnd = 0, line_rnd_up = 0;
+
+	// device
+	bool inited = false;
+	int device = -1;
+	int cu_count = 0;
+	bool tables_dirty = true;
+	DevRing tables_ring;
+	std::vector<uint8_t> tables_host[DevRing::N];
+	// staging for the host-pointer entry points
+	void* stage[3] = {nullptr, nullptr, nullptr};
+	size_t stage_cap[3] = {0, 0, 0};
+	hipStream_t own_stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+	State()
+	{
+		memset(bank, 0, sizeof bank);
+		memset(slut, 0, sizeof slut);
+		memset(plut, 0, sizeof plut);
+		lfsr.reseed(0xdeadbeefu);   // vfgs_hw.c:52-55
+	}
+};
+
+State& S()
+{
+	static State s;
+	return s;
+}
+
+std::mutex g_mu;
+
+int ensure_init(int device)
+{
+	State& s = S();
+	if (s.inited && (device < 0 || device == s.device))
+		return 0;
+	if (s.inited)
+		return fail(1, "vfgs_hip_init: already initialised on device %d", s.device);
+	int n = 0;
+	HIP_TRY(hipGetDeviceCount(&n));
+	if (n <= 0)
+		return fail(2, "no HIP device visible");
+	if (device < 0)
+		HIP_TRY(hipGetDevice(&device));
+	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(3, "device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
+	s.cu_count = prop.multiProcessorCount;
+	s.device = device;
+	HIP_TRY(hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreate(&s.ev0));
+	HIP_TRY(hipEventCreate(&s.ev1));
+	s.inited = true;
+	return 0;
+}
+
+// Build the slot-interleaved LDS image of vfgs_layout.h from the mirror.
+template <int CSUBX, int CSUBY>
+void build_tables(const State& s, std::vector<uint8_t>& img)
+{
+	using L = vfgs::TableLayout<CSUBX, CSUBY>;
+	img.assign(L::BYTES, 0);
+	for (int r = 0; r < 64; r++)
+		for (int x = 0; x < 64; x++)
+			for (int k = 0; k < vfgs::kSlots; k++)
+				img[L::LUMA_OFF + r * L::LRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[0][k][r][x];
+	for (int r = 0; r < L::CH; r++)
+		for (int x = 0; x < L::CW; x++)
+			for (int k = 0; k < vfgs::kSlots; k++)
+				img[L::CHROMA_OFF + r * L::CRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[1][k][r][x];
+	uint32_t* lut = (uint32_t*)(img.data() + L::LUT_OFF);
+	for (int c = 0; c < 3; c++)
+		for (int i = 0; i < 256; i++)
+		{
+			const int slot = s.plut[c][i] >> 4;   // vfgs_hw.c:212
+			const uint32_t sel = slot < vfgs::kSlots ? (uint32_t)slot : 0x0cu;  // slot 8: the reference's all-zero bank
+			lut[c * 256 + i] = sel | ((uint32_t)s.slut[c][i] << 16);
+		}
+}
+
+int check_luts(const State& s)
+{
+	for (int c = 0; c < 3; c++)
+		for (int i = 0; i < 256; i++)
+			if ((s.plut[c][i] >> 4) > vfgs::kSlots)
+				return fail(4, "pattern LUT %d[%d] selects slot %d > 8 (undefined in the reference, vfgs_hw.c:49,212)", c, i, s.plut[c][i] >> 4);
+	return 0;
+}
+
+int upload_tables(State& s, hipStream_t stream)
+{
+	if (!s.tables_dirty && s.tables_ring.current())
+		return 0;
+	if (int e = check_luts(s)) return e;
+	void* dst = nullptr;
+	const int bytes = vfgs::table_bytes(s.csubx, s.csuby);
+	HIP_TRY(s.tables_ring.next(bytes, &dst));
+	std::vector<uint8_t>& img = s.tables_host[s.tables_ring.cur];
+	if (s.csubx == 2 && s.csuby == 2) build_tables<2, 2>(s, img);
+	else if (s.csubx == 2 && s.csuby == 1) build_tables<2, 1>(s, img);
+	else if (s.csubx == 1 && s.csuby == 1) build_tables<1, 1>(s, img);
+	else build_tables<1, 2>(s, img);
+	HIP_TRY(hipMemcpyAsync(dst, img.data(), bytes, hipMemcpyHostToDevice, stream));
+	s.tables_dirty = false;
+	return 0;
+}
+
+int upload_stream(State& s, uint64_t lo, uint64_t hi, hipStream_t stream)
+{
+	HIP_TRY(s.lfsr.ensure(lo, hi, stream));
+	return 0;
+}
+
+struct StripePlan {
+	uint64_t cur0, up0;   // positions for the first block row of the processed part
+};
+
+// The seed state machine of vfgs_add_grain_line (vfgs_hw.c:291-298, 309-310) run over lines
+// [y, y+n) on stream *positions*; records the registers of line `mark`.
+StripePlan advance_seeds(State& s, unsigned y, unsigned n, unsigned nblk, unsigned mark)
+{
+	StripePlan p{0, 0};
+	for (unsigned yy = y; yy < y + n; yy++)
+	{
+		if (yy && (yy & 15) == 0)
+		{
+			s.line_rnd_up = s.line_rnd;
+			s.line_rnd = s.rnd;
+		}
+		s.rnd_up = s.line_rnd_up;
+		s.rnd = s.line_rnd;
+		if (yy == mark)
+		{
+			p.cur0 = s.rnd;
+			p.up0 = s.rnd_up;
+		}
+		s.rnd += nblk;
+		s.rnd_up += nblk;
+	}
+	return p;
+}
+
+int check_geometry(const State& s, const void* dY, const void* dU, const void* dV, unsigned width, unsigned stride, unsigned cstride)
+{
+	const unsigned sz = s.bs ? 2 : 1;
+	const unsigned nblk = (width + 15) / 16;
+	if (width <= 128)   // vfgs_hw.c:168
+		return fail(5, "width %u: the hardware layer requires width > 128 (vfgs_hw.c:168)", width);
+	if (stride < nblk * 16 || cstride < nblk * 16 / s.csubx)
+		return fail(6, "stride %u/%u too small: whole 16-sample blocks are written (need >= %u/%u)", stride, cstride, nblk * 16, nblk * 16 / s.csubx);
+	if (((uintptr_t)dY | (uintptr_t)dU | (uintptr_t)dV) & 15)
+		return fail(7, "plane pointers must be 16-byte aligned");
+	if ((stride * sz) % 16 || (cstride * sz) % 16)
+		return fail(8, "row pitch must be a multiple of 16 bytes");
+	if (s.scale_shift + s.bs < 8 || s.scale_shift + s.bs > 13)   // vfgs_hw.c:170
+		return fail(9, "scale_shift out of range (vfgs_hw.c:170)");
+	return 0;
+}
+
+// Core: launch the kernel over `nframes` frames, lines [part_y, part_y+part_h) of each.
+int run_device(void* dY, void* dU, void* dV, unsigned width, unsigned frame_y, unsigned frame_h,
+               unsigned part_y, unsigned part_h, unsigned stride, unsigned cstride, unsigned nframes,
+               uint64_t ypitch, uint64_t cpitch, hipStream_t stream)
+{
+	State& s = S();
+	if (int e = ensure_init(-1)) return e;
+	if (int e = check_geometry(s, dY, dU, dV, width, stride, cstride)) return e;
+	if (part_h == 0 || nframes == 0) return 0;
+
+	const unsigned nblk = (width + 15) / 16;
+	KernelArgs a{};
+	a.Y = (uint8_t*)dY; a.U = (uint8_t*)dU; a.V = (uint8_t*)dV;
+	a.y_frame_pitch = ypitch; a.c_frame_pitch = cpitch;
+	a.y0 = (int)part_y; a.nlines = (int)part_h;
+	a.nblk = (int)nblk;
+	a.ntx = (int)((16 * nblk + 8 + vfgs::kTilePx - 1) / vfgs::kTilePx);
+	a.nbr = (int)(((part_y + part_h - 1) >> 4) - (part_y >> 4) + 1);
+	a.stride = (int)stride; a.cstride = (int)cstride;
+	a.nframes = (int)nframes;
+	a.scale_shift = s.scale_shift;
+	a.ylo = s.ymin << s.bs; a.yhi = s.ymax << s.bs;
+	a.clo = s.cmin << s.bs; a.chi = s.cmax << s.bs;
+
+	// seeds: every frame of the batch runs the full state machine; frame 0's part gives the offsets
+	uint64_t first_cur = 0, first_up = 0, second_cur = 0, lo = ~0ull, hi = 0;
+	for (unsigned f = 0; f < nframes; f++)
+	{
+		StripePlan p = advance_seeds(s, frame_y, frame_h, nblk, part_y);
+		if (f == 0) { first_cur = p.cur0; first_up = p.up0; }
+		if (f == 1) second_cur = p.cur0;
+		if (f >= 2 && p.cur0 != first_cur + (second_cur - first_cur) * f)
+			return fail(10, "internal: batch seed positions are not equidistant");
+		lo = std::min(lo, std::min(p.cur0, p.up0));
+		hi = std::max(hi, p.cur0 + (uint64_t)a.nbr * nblk);
+		hi = std::max(hi, p.up0 + nblk);
+	}
+	if (int e = upload_tables(s, stream)) return e;
+	if (int e = upload_stream(s, lo, hi, stream)) return e;
+	a.tables = (const uint8_t*)s.tables_ring.current();
+	a.stream = s.lfsr.dev();
+	a.cur_bit0 = (uint32_t)(first_cur - s.lfsr.base_bit());
+	a.up_bit0 = (uint32_t)(first_up - s.lfsr.base_bit());
+	a.frame_bit_step = nframes > 1 ? (uint32_t)(second_cur - first_cur) : 0;
+
+	const long total = (long)a.nbr * a.ntx * a.nframes;
+	const int grid = (int)std::min<long>((total + vfgs::kWavesPerWG - 1) / vfgs::kWavesPerWG, s.cu_count);
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, grid, stream));
+	return 0;
+}
+
+// host-memory stripe: stage through device buffers (compatibility path of the line API)
+int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride)
+{
+	State& s = S();
+	if (int e = ensure_init(-1)) return e;
+	if (height == 0) return 0;
+	const unsigned sz = s.bs ? 2 : 1;
+	const unsigned nblk = (width + 15) / 16;
+	// rows of each plane touched by lines [y, y+height)
+	const unsigned crow0 = y / s.csuby;
+	const unsigned crows = (y + height - 1) / s.csuby - crow0 + 1;
+	const unsigned rows[3] = {height, crows, crows};
+	const unsigned rowlen[3] = {nblk * 16 * sz, nblk * 16 / s.csubx * sz, nblk * 16 / s.csubx * sz};  // bytes the reference touches per row
+	const unsigned dpitch[3] = {(rowlen[0] + 255) & ~255u, (rowlen[1] + 255) & ~255u, (rowlen[2] + 255) & ~255u};
+	const size_t spitch[3] = {(size_t)stride * sz, (size_t)cstride * sz, (size_t)cstride * sz};
+	void* host[3] = {Y, U, V};
+	for (int i = 0; i < 3; i++)
+	{
+		const size_t need = (size_t)dpitch[i] * rows[i] + 256;
+		if (s.stage_cap[i] < need)
+		{
+			if (s.stage[i]) HIP_TRY(hipFree(s.stage[i]));
+			s.stage[i] = nullptr; s.stage_cap[i] = 0;
+			HIP_TRY(hipMalloc(&s.stage[i], need));
+			s.stage_cap[i] = need;
+		}
+		HIP_TRY(hipMemcpy2DAsync(s.stage[i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, s.own_stream));
+	}
+	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], width, y, height, y, height,
+	                       dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, s.own_stream))
+		return e;
+	for (int i = 0; i < 3; i++)
+		HIP_TRY(hipMemcpy2DAsync(host[i], spitch[i], s.stage[i], dpitch[i], rowlen[i], rows[i], hipMemcpyDeviceToHost, s.own_stream));
+	HIP_TRY(hipStreamSynchronize(s.own_stream));
+	return 0;
+}
+
+}  // namespace
+
+// ========================================================================================
+// C ABI
+
+extern "C" {
+
+void vfgs_set_luma_pattern(int index, signed char* P)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_luma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:316)"); }
+	memcpy(S().bank[0][index], P, 64 * 64);   // vfgs_hw.c:317
+	S().tables_dirty = true;
+}
+
+void vfgs_set_chroma_pattern(int index, signed char* P)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_chroma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:322)"); }
+	for (int i = 0; i < 64 / s.csuby; i++)   // vfgs_hw.c:323-324: pitch from csuby, length from csubx
+		memcpy(s.bank[1][index][i], P + (64 / s.csuby) * i, 64 / s.csubx);
+	s.tables_dirty = true;
+}
+
+void vfgs_set_scale_lut(int c, unsigned char lut[])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (c < 0 || c > 2) { fail(21, "vfgs_set_scale_lut: component %d", c); die("bad component (vfgs_hw.c:329)"); }
+	memcpy(S().slut[c], lut, 256);
+	S().tables_dirty = true;
+}
+
+void vfgs_set_pattern_lut(int c, unsigned char lut[])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (c < 0 || c > 2) { fail(21, "vfgs_set_pattern_lut: component %d", c); die("bad component (vfgs_hw.c:335)"); }
+	memcpy(S().plut[c], lut, 256);
+	S().tables_dirty = true;
+}
+
+void vfgs_set_seed(unsigned int seed)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	s.lfsr.reseed(seed << 1);   // vfgs_hw.c:343
+	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
+}
+
+void vfgs_set_scale_shift(int shift)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (shift < 2 || shift >= 8) { fail(22, "vfgs_set_scale_shift: %d", shift); die("shift out of 2..7 (vfgs_hw.c:348)"); }
+	S().scale_shift = shift + 6 - S().bs;   // vfgs_hw.c:349
+}
+
+void vfgs_set_depth(int depth)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	if (depth != 8 && depth != 10) { fail(23, "vfgs_set_depth: %d", depth); die("depth must be 8 or 10 (vfgs_hw.c:354)"); }
+	s.scale_shift += s.bs - (depth - 8);     // vfgs_hw.c:356-359
+	s.bs = depth - 8;
+}
+
+void vfgs_set_legal_range(int legal)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	s.ymin = s.cmin = legal ? 16 : 0;        // vfgs_hw.c:366-378
+	s.ymax = legal ? 235 : 255;
+	s.cmax = legal ? 240 : 255;
+}
+
+void vfgs_set_chroma_subsampling(int subx, int suby)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if ((subx != 1 && subx != 2) || (suby != 1 && suby != 2)) { fail(24, "vfgs_set_chroma_subsampling: %d,%d", subx, suby); die("subsampling must be 1 or 2 (vfgs_hw.c:384-385)"); }
+	S().csubx = subx;
+	S().csuby = suby;
+	S().tables_dirty = true;
+}
+
+void vfgs_add_grain_line(void* Y, void* U, void* V, int y, int width)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	// a line call carries no pitch: a 1-line stripe never uses it
+	if (run_host(Y, U, V, (unsigned)y, (unsigned)width, 1, 0, 0))
+		die("vfgs_add_grain_line");
+}
+
+void vfgs_add_grain_stripe(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (run_host(Y, U, V, y, width, height, stride, cstride))
+		die("vfgs_add_grain_stripe");
+}
+
+void vfgs_hip_reset_state(void)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	memset(s.bank, 0, sizeof s.bank);
+	memset(s.slut, 0, sizeof s.slut);
+	memset(s.plut, 0, sizeof s.plut);
+	s.scale_shift = 5 + 6;
+	s.bs = 0;
+	s.ymin = s.cmin = 0;
+	s.ymax = s.cmax = 255;
+	s.csubx = s.csuby = 2;
+	s.lfsr.reseed(0xdeadbeefu);
+	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
+	s.tables_dirty = true;
+}
+
+int vfgs_hip_init(int device)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	return ensure_init(device);
+}
+
+void vfgs_hip_shutdown(void)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	if (!s.inited) return;
+	(void)hipDeviceSynchronize();
+	s.tables_ring.release();
+	s.lfsr.release();
+	for (int i = 0; i < 3; i++) { if (s.stage[i]) (void)hipFree(s.stage[i]); s.stage[i] = nullptr; s.stage_cap[i] = 0; }
+	if (s.own_stream) (void)hipStreamDestroy(s.own_stream);
+	if (s.ev0) (void)hipEventDestroy(s.ev0);
+	if (s.ev1) (void)hipEventDestroy(s.ev1);
+	s.own_stream = nullptr; s.ev0 = s.ev1 = nullptr;
+	s.tables_dirty = true;
+	s.inited = false;
+}
+
+int vfgs_hip_add_grain_stripe_dev(void* dY, void* dU, void* dV, unsigned y, unsigned width, unsigned height,
+                                  unsigned stride, unsigned cstride, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	return run_device(dY, dU, dV, width, y, height, y, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+}
+
+int vfgs_hip_add_grain_frame_dev(void* dY, void* dU, void* dV, unsigned width, unsigned height,
+                                 unsigned stride, unsigned cstride, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	return run_device(dY, dU, dV, width, 0, height, 0, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+}
+
+int vfgs_hip_add_grain_frame_part_dev(void* dY, void* dU, void* dV, unsigned width, unsigned frame_height,
+                                      unsigned part_y, unsigned part_height, unsigned stride, unsigned cstride, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
+	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	return run_device(dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+}
+
+int vfgs_hip_add_grain_frames_dev(void* dY, void* dU, void* dV, unsigned width, unsigned height, unsigned stride,
+                                  unsigned cstride, unsigned nframes, uint64_t y_frame_pitch_bytes,
+                                  uint64_t c_frame_pitch_bytes, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
+	return run_device(dY, dU, dV, width, 0, height, 0, height, stride, cstride, nframes,
+	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
+}
+
+void vfgs_hip_get_seed_state(uint32_t out[4])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	out[0] = s.lfsr.window(s.rnd);
+	out[1] = s.lfsr.window(s.rnd_up);
+	out[2] = s.lfsr.window(s.line_rnd);
+	out[3] = s.lfsr.window(s.line_rnd_up);
+}
+
+int vfgs_hip_last_error(void) { return g_err; }
+const char* vfgs_hip_last_error_string(void) { return g_errstr.c_str(); }
+
+int vfgs_hip_timer_begin(void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (int e = ensure_init(-1)) return e;
+	HIP_TRY(hipEventRecord(S().ev0, (hipStream_t)stream));
+	return 0;
+}
+
+int vfgs_hip_timer_end(void* stream, float* elapsed_ms)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (int e = ensure_init(-1)) return e;
+	HIP_TRY(hipEventRecord(S().ev1, (hipStream_t)stream));
+	HIP_TRY(hipEventSynchronize(S().ev1));
+	HIP_TRY(hipEventElapsedTime(elapsed_ms, S().ev0, S().ev1));
+	return 0;
+}
+
+int vfgs_hip_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* name, int name_len)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (int e = ensure_init(-1)) return e;
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, S().device));
+	if (cu_count) *cu_count = prop.multiProcessorCount;
+	if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+	if (clock_khz) *clock_khz = prop.clockRate;
+	if (name && name_len > 0) { strncpy(name, prop.name, name_len - 1); name[name_len - 1] = 0; }
+	return 0;
+}
+
+}  // extern "C"

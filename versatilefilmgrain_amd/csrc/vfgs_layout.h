@@ -1,0 +1,63 @@
+// Shared between the host state machine (vfgs_host.cpp) and the gfx950 kernels
+// (vfgs_kernel.hip): the LDS image of the pattern banks + LUTs and the launch record.
+#pragma once
+#include <stdint.h>
+
+namespace vfgs {
+
+constexpr int kSlots = 8;        // pattern slots per component, vfgs_hw.h:49
+constexpr int kTilePx = 128;     // luma samples per tile row (8 grain blocks)
+constexpr int kWavesPerWG = 16;  // 1024-thread workgroups, one LDS image each
+constexpr int kBlock = 16;       // luma samples per grain block
+
+// LDS / device image of everything the kernel looks up.
+//
+// Pattern banks are stored "slot-interleaved": for every (row, column) position the
+// eight slots' int8 values sit in 8 consecutive bytes, so the LDS address of a sample's
+// pattern data does NOT depend on the sample's intensity (the slot is picked afterwards
+// in registers with v_perm_b32).  A lane's 8 samples are then 4 ds_read_b128.
+// Each bank row is padded by one 16-byte slot so consecutive rows rotate through the
+// sixteen 16-byte LDS slots of a 256-byte bank row.
+//
+// LUT entry (one dword per 8-bit intensity, per component):
+//   bits  7:0  byte selector for v_perm_b32: slot 0..7, or 0x0c (constant zero) for slot 8
+//              (the reference's never-written 9th slot, vfgs_hw.c:49)
+//   bits 23:16 scale factor (sLUT)
+template <int CSUBX, int CSUBY>
+struct TableLayout {
+	static constexpr int LRS = 64 * kSlots + 16;        // luma bank row stride, bytes
+	static constexpr int CW = 64 / CSUBX;               // chroma bank columns actually addressable
+	static constexpr int CH = 64 / CSUBY;               // chroma bank rows
+	static constexpr int CRS = CW * kSlots + 16;        // chroma bank row stride, bytes
+	static constexpr int LUMA_OFF = 0;
+	static constexpr int CHROMA_OFF = 64 * LRS;
+	static constexpr int LUT_OFF = CHROMA_OFF + CH * CRS;
+	static constexpr int BYTES = LUT_OFF + 3 * 256 * 4;
+	static_assert(BYTES % 16 == 0, "image is copied in 16-byte pieces");
+};
+
+// One launch = nframes x nbr block rows x ntx tiles; one tile = 128 luma samples x one
+// block row (16 luma lines) of Y plus the co-located Cb/Cr samples, owned by ONE wavefront.
+struct KernelArgs {
+	uint8_t* Y;               // line `y0` of frame 0 (device)
+	uint8_t* U;               // chroma row y0/csuby of frame 0
+	uint8_t* V;
+	uint64_t y_frame_pitch;   // bytes from frame f to frame f+1 (batched launches)
+	uint64_t c_frame_pitch;
+	const uint32_t* stream;   // LFSR bit stream cache (device), bit m = word[m>>5] >> (m&31)
+	const uint8_t* tables;    // TableLayout image (device)
+	uint32_t cur_bit0;        // stream bit of the register of block 0, first block row of the stripe, frame 0
+	uint32_t up_bit0;         // same for the "upper" register of that first block row
+	uint32_t frame_bit_step;  // stream bits between consecutive frames of a batch
+	int y0;                   // absolute luma line of the first line of the stripe
+	int nlines;               // luma lines in the stripe
+	int nblk;                 // 16-sample blocks per line = ceil(width/16), vfgs_hw.c:301
+	int ntx;                  // tiles per block row
+	int nbr;                  // block rows touched by the stripe
+	int stride, cstride;      // samples
+	int nframes;
+	int scale_shift;          // vfgs_hw.c:56 (already includes +6-bs)
+	int ylo, yhi, clo, chi;   // clip bounds in sample units (I_min<<bs ...), vfgs_hw.c:264-267
+};
+
+}  // namespace vfgs

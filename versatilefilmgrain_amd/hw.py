@@ -1,0 +1,131 @@
+"""ctypes mirror of include/vfgs_hip.h.
+
+Same names and argument meaning as the reference hardware-layer interface
+(/root/reference/src/vfgs_hw.h:51-62) plus the vfgs_hip_* extensions.  The library state is
+a process-global singleton exactly like the reference's (vfgs_hw.c:49-68), so ``VfgsHip`` is
+a namespace around that singleton, not an object with private state.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+from .build import LIB
+
+_lib = None
+
+
+class VfgsHipError(RuntimeError):
+    pass
+
+
+def load(path: Path | None = None) -> C.CDLL:
+    """dlopen libvfgs_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(path or LIB)
+    if not path.exists():
+        raise VfgsHipError(f"{path} not built: run `python -m versatilefilmgrain_amd.build` "
+                           "(needs hipcc); there is no CPU fallback")
+    lib = C.CDLL(str(path))
+    vp, u, i = C.c_void_p, C.c_uint, C.c_int
+    lib.vfgs_set_luma_pattern.argtypes = [i, vp]
+    lib.vfgs_set_chroma_pattern.argtypes = [i, vp]
+    lib.vfgs_set_scale_lut.argtypes = [i, vp]
+    lib.vfgs_set_pattern_lut.argtypes = [i, vp]
+    lib.vfgs_set_seed.argtypes = [u]
+    lib.vfgs_set_scale_shift.argtypes = [i]
+    lib.vfgs_set_depth.argtypes = [i]
+    lib.vfgs_set_legal_range.argtypes = [i]
+    lib.vfgs_set_chroma_subsampling.argtypes = [i, i]
+    lib.vfgs_add_grain_line.argtypes = [vp, vp, vp, i, i]
+    lib.vfgs_add_grain_stripe.argtypes = [vp, vp, vp, u, u, u, u, u]
+    lib.vfgs_hip_init.argtypes = [i]
+    lib.vfgs_hip_add_grain_stripe_dev.argtypes = [vp, vp, vp, u, u, u, u, u, vp]
+    lib.vfgs_hip_add_grain_frame_dev.argtypes = [vp, vp, vp, u, u, u, u, vp]
+    lib.vfgs_hip_add_grain_frame_part_dev.argtypes = [vp, vp, vp, u, u, u, u, u, u, vp]
+    lib.vfgs_hip_add_grain_frames_dev.argtypes = [vp, vp, vp, u, u, u, u, u, C.c_uint64, C.c_uint64, vp]
+    lib.vfgs_hip_get_seed_state.argtypes = [vp]
+    lib.vfgs_hip_last_error_string.restype = C.c_char_p
+    lib.vfgs_hip_timer_begin.argtypes = [vp]
+    lib.vfgs_hip_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.vfgs_hip_device_info.argtypes = [C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
+    _lib = lib
+    return lib
+
+
+EXPORTS = [
+    # drop-in, vfgs_hw.h:51-62
+    "vfgs_set_luma_pattern", "vfgs_set_chroma_pattern", "vfgs_set_scale_lut", "vfgs_set_pattern_lut",
+    "vfgs_set_seed", "vfgs_set_scale_shift", "vfgs_set_depth", "vfgs_set_legal_range",
+    "vfgs_set_chroma_subsampling", "vfgs_add_grain_line",
+    # extensions
+    "vfgs_add_grain_stripe", "vfgs_hip_init", "vfgs_hip_shutdown", "vfgs_hip_reset_state",
+    "vfgs_hip_add_grain_stripe_dev", "vfgs_hip_add_grain_frame_dev", "vfgs_hip_add_grain_frame_part_dev",
+    "vfgs_hip_add_grain_frames_dev", "vfgs_hip_get_seed_state", "vfgs_hip_last_error",
+    "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
+]
+
+
+def _b(data):
+    return (C.c_char * len(data)).from_buffer_copy(bytes(data))
+
+
+class VfgsHip:
+    """Namespace over the library singleton (same method names as the test-side wrappers)."""
+
+    def __init__(self, device: int | None = None, reset: bool = True):
+        self.lib = load()
+        if device is not None:
+            self._ck(self.lib.vfgs_hip_init(device))
+        if reset:
+            self.lib.vfgs_hip_reset_state()
+
+    def _ck(self, rc):
+        if rc:
+            raise VfgsHipError(f"libvfgs_hip error {rc}: {self.lib.vfgs_hip_last_error_string().decode()}")
+
+    # ---- drop-in setters
+    def set_luma_pattern(self, i, P):       self.lib.vfgs_set_luma_pattern(i, _b(P))
+    def set_chroma_pattern(self, i, P):     self.lib.vfgs_set_chroma_pattern(i, _b(P))
+    def set_scale_lut(self, c, lut):        self.lib.vfgs_set_scale_lut(c, _b(lut))
+    def set_pattern_lut(self, c, lut):      self.lib.vfgs_set_pattern_lut(c, _b(lut))
+    def set_seed(self, s):                  self.lib.vfgs_set_seed(s & 0xFFFFFFFF)
+    def set_scale_shift(self, s):           self.lib.vfgs_set_scale_shift(s)
+    def set_depth(self, d):                 self.lib.vfgs_set_depth(d)
+    def set_legal_range(self, l):           self.lib.vfgs_set_legal_range(l)
+    def set_chroma_subsampling(self, x, y): self.lib.vfgs_set_chroma_subsampling(x, y)
+
+    # ---- host-memory processing (pointers are plain integers / ctypes addresses)
+    def add_grain_line(self, Y, U, V, y, width):
+        self.lib.vfgs_add_grain_line(Y, U, V, y, width)
+
+    def add_grain_stripe(self, Y, U, V, y, width, height, stride, cstride):
+        self.lib.vfgs_add_grain_stripe(Y, U, V, y, width, height, stride, cstride)
+
+    # ---- device-resident processing
+    def add_grain_stripe_dev(self, dY, dU, dV, y, width, height, stride, cstride, stream=0):
+        self._ck(self.lib.vfgs_hip_add_grain_stripe_dev(dY, dU, dV, y, width, height, stride, cstride, stream))
+
+    def add_grain_frame_dev(self, dY, dU, dV, width, height, stride, cstride, stream=0):
+        self._ck(self.lib.vfgs_hip_add_grain_frame_dev(dY, dU, dV, width, height, stride, cstride, stream))
+
+    def add_grain_frame_part_dev(self, dY, dU, dV, width, frame_height, part_y, part_height, stride, cstride, stream=0):
+        self._ck(self.lib.vfgs_hip_add_grain_frame_part_dev(dY, dU, dV, width, frame_height, part_y, part_height,
+                                                            stride, cstride, stream))
+
+    def add_grain_frames_dev(self, dY, dU, dV, width, height, stride, cstride, nframes, ypitch, cpitch, stream=0):
+        self._ck(self.lib.vfgs_hip_add_grain_frames_dev(dY, dU, dV, width, height, stride, cstride, nframes,
+                                                        ypitch, cpitch, stream))
+
+    def seed_state(self):
+        out = (C.c_uint32 * 4)()
+        self.lib.vfgs_hip_get_seed_state(out)
+        return tuple(out)
+
+    def device_info(self):
+        cu, lds, clk = C.c_int(), C.c_int(), C.c_int()
+        name = C.create_string_buffer(128)
+        self._ck(self.lib.vfgs_hip_device_info(C.byref(cu), C.byref(lds), C.byref(clk), name, 128))
+        return {"cu_count": cu.value, "lds_per_cu": lds.value, "clock_khz": clk.value, "name": name.value.decode()}
