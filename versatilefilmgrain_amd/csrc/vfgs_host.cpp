@@ -450,7 +450,9 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 	const unsigned rows[3] = {height, crows, crows};
 	const unsigned rowlen[3] = {nblk * 16 * sz, nblk * 16 / s.csubx * sz, nblk * 16 / s.csubx * sz};  // bytes the reference touches per row
 	const unsigned dpitch[3] = {(rowlen[0] + 255) & ~255u, (rowlen[1] + 255) & ~255u, (rowlen[2] + 255) & ~255u};
-	const size_t spitch[3] = {(size_t)stride * sz, (size_t)cstride * sz, (size_t)cstride * sz};
+	// (a 1-line stripe from vfgs_add_grain_line carries no pitch; it needs none)
+	const size_t spitch[3] = {std::max<size_t>((size_t)stride * sz, rowlen[0]), std::max<size_t>((size_t)cstride * sz, rowlen[1]),
+	                          std::max<size_t>((size_t)cstride * sz, rowlen[2])};
 	void* host[3] = {Y, U, V};
 	for (int i = 0; i < 3; i++)
 	{
