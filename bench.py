@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path (grain synthesis over Y/Cb/Cr) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by
+torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json `metric` / configs[4]): 7680x4320 10-bit 4:2:0, cfg fgs_sei
+(8 luma patterns, per-sample pattern selection), seed 12345, synthetic frames of uniformly
+random 10-bit samples generated on the GPU and resident in HBM before the timed region.
+
+A "step" processes `N x batch` frames: every frame is split into N stripes of whole 16-line
+block rows, rank r owns stripe r of every frame (no collective, no halo -- DESIGN.md
+"multi-GPU"), so per-GPU work per step is one frame's worth at every N ("weak").  At N=1 a
+step is `batch` whole frames in one launch.
+
+`value`   = luma pixels of all frames of all ranks / wall time          [Mpixels/s]
+`roofline`= algorithmic bytes per launch (4 B per Y/Cb/Cr sample: one read + one write of
+            2 bytes) / mean launch duration from HIP events on the launching stream.
+`cpu_baseline` = the REAL reference hardware layer (oracle/_ref/libvfgs_ref.so, kind
+            "reference") if that prebuilt file travelled to this box, else this repo's oracle
+            ("port"), one host core, on a bounded number of frames of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+W, H, DEPTH, SUBX, SUBY = 7680, 4320, 10, 2, 2
+TRACE = "fgs_sei_10_420"
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); float4 copy reaches 6.29 TB/s
+
+
+def split_rows(nbr, n):
+    """nbr block rows -> n contiguous parts, sizes differ by at most one."""
+    base, extra = divmod(nbr, n)
+    out, r = [], 0
+    for i in range(n):
+        k = base + (1 if i < extra else 0)
+        out.append((r, k))
+        r += k
+    return out
+
+
+def cpu_baseline(seconds=10.0):
+    """Reference (or oracle) hot path on ONE host core over whole 4320p frames."""
+    import numpy as np
+    import vfgs_testlib as T
+
+    rec = T.load_trace(TRACE)
+    lib = T.oracle_lib()
+    frame, _ = T.lcg_frames(W, H, DEPTH, SUBX, SUBY, 1)
+    f = frame[0]
+    if T.have_reference():
+        kind, hw = "reference", T.ReferenceHW()
+        T.replay(hw, rec)
+        line = C.cast(hw.lib.vfgs_add_grain_line, C.c_void_p)
+
+        def run(fr):
+            lib.vfgs_oracle_drive_lines(line, C.c_void_p(fr.Y.ctypes.data), C.c_void_p(fr.U.ctypes.data),
+                                        C.c_void_p(fr.V.ctypes.data), fr.width, fr.height, fr.stride, fr.cstride, 2, SUBY)
+    else:
+        kind, hw = "port", T.OracleHW()
+        T.replay(hw, rec)
+
+        def run(fr):
+            hw.add_grain_frame(fr)
+    pristine = [p.copy() for p in f.planes()]
+    n, spent, best = 0, 0.0, 1e9
+    while spent < seconds and n < 200:
+        for p, q in zip(f.planes(), pristine):
+            np.copyto(p, q)               # untimed: same content every frame
+        t0 = time.perf_counter()
+        run(f)
+        dt = time.perf_counter() - t0
+        spent += dt
+        best = min(best, dt)
+        n += 1
+    return {"value": round(W * H * n / spent / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+            "sample": f"{n} frames 7680x4320 10-bit 4:2:0 fgs_sei, hot path only (line loop of vfgs_main.c:664-682), "
+                      f"mean {spent / n * 1e3:.1f} ms/frame, best {best * 1e3:.1f} ms/frame",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="frames per launch per rank-stripe set")
+    ap.add_argument("--pool", type=int, default=24, help="distinct frame buffers cycled through (>= 256 MiB of data)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import vfgs_testlib as T
+    from versatilefilmgrain_amd import hw
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    h = hw.VfgsHip(device=local)
+    T.replay(h, T.load_trace(TRACE))     # programs banks/LUTs/shift/depth/subsampling/seed 12345
+
+    nbr = (H + 15) // 16
+    row0, nrows = split_rows(nbr, world)[rank]
+    part_y, part_h = row0 * 16, min(nrows * 16, H - row0 * 16)
+    frames_per_launch = world * args.batch       # rank r: its stripe of each of these frames
+    stride, cstride = W, W // SUBX
+    ypitch = part_h * stride * 2                 # bytes between consecutive frames' stripes
+    cpitch = (part_h // SUBY) * cstride * 2
+    pool = max(2, min(args.pool, args.steps + args.warmup))
+    g = torch.Generator(device="cuda").manual_seed(1 + rank)
+    Y = torch.randint(0, 1024, (pool, frames_per_launch, part_h, stride), dtype=torch.int16, device="cuda", generator=g)
+    U = torch.randint(0, 1024, (pool, frames_per_launch, part_h // SUBY, cstride), dtype=torch.int16, device="cuda", generator=g)
+    V = torch.randint(0, 1024, (pool, frames_per_launch, part_h // SUBY, cstride), dtype=torch.int16, device="cuda", generator=g)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        s = i % pool
+        h.add_grain_frames_part_dev(Y[s].data_ptr(), U[s].data_ptr(), V[s].data_ptr(), W, H, part_y, part_h,
+                                    stride, cstride, frames_per_launch, ypitch, cpitch, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    launch_ms = ev0.elapsed_time(ev1) / args.steps     # same stream as the kernels (torch's current stream)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames_total = args.steps * frames_per_launch          # whole frames finished by all ranks together
+        mpix = frames_total * W * H / elapsed / 1e6
+        samples_per_launch = frames_per_launch * (part_h * W + 2 * (part_h // SUBY) * (W // SUBX))
+        bytes_per_launch = 4 * samples_per_launch              # 2 B read + 2 B written per sample
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"            # PMC-derived bytes per launch, if collected
+        if tf.exists() and world == 1 and args.batch == 1:
+            traffic = json.loads(tf.read_text()).get("bytes_per_launch")
+        out = {
+            "metric": "Mpixels/s (Y+UV) + achieved HBM GB/s vs roofline, 4320p 10-bit 4:2:0",
+            "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "7680x4320 10-bit 4:2:0, cfg fgs_sei (8 luma patterns), seed 12345, uniform random samples",
+                       "frames_per_step": frames_per_launch, "stripe_split": f"{world} x block-row stripes",
+                       "pool_frames": pool * frames_per_launch, "msamples_per_s": round(mpix * 1.5, 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "grain_kernel<10,2,2>", "launch_us": round(launch_ms * 1e3, 2),
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

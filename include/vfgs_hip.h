@@ -101,6 +101,25 @@ int vfgs_hip_add_grain_frames_dev(void* dY, void* dU, void* dV, unsigned width, 
                                   uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes,
                                   void* stream);
 
+/* Batch + stripe split combined: lines [part_y, part_y+part_height) of each of `nframes`
+ * consecutive frames in ONE launch (what one rank of an N-GPU stripe split runs per step);
+ * pointers address line part_y of frame 0; seeds advance as for whole frames. */
+int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned width,
+                                       unsigned frame_height, unsigned part_y, unsigned part_height,
+                                       unsigned stride, unsigned cstride, unsigned nframes,
+                                       uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes,
+                                       void* stream);
+
+/* Out-of-place form of the call above: reads sY/sU/sV, writes dY/dU/dV (same geometry and
+ * pitches; src == dst is allowed and is what the in-place entry points pass).  This is how a
+ * decoder uses film grain -- the clean picture stays a reference frame, the grained copy goes
+ * to the display queue -- and it is the faster form: on MI355X an in-place read-modify-write
+ * stream tops out at ~5.5 TB/s, a src->dst stream at ~6.3 TB/s (tools/copy_ceiling.hip). */
+int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV,
+                                unsigned width, unsigned frame_height, unsigned part_y, unsigned part_height,
+                                unsigned stride, unsigned cstride, unsigned nframes,
+                                uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes, void* stream);
+
 /* {rnd, rnd_up, line_rnd, line_rnd_up} as the reference would hold them (vfgs_hw.c:52-55). */
 void vfgs_hip_get_seed_state(uint32_t out[4]);
 

@@ -424,6 +424,24 @@ void vfgs_oracle_add_grain_frame_closed_form(vfgs_oracle* o, void* Y, void* U, v
 	free(cur); free(up0); free(ycopy); free(ucopy); free(vcopy);
 }
 
+/* ---- driving a foreign line function (the real reference) ------------------ */
+
+void vfgs_oracle_drive_lines(vfgs_line_fn fn, void* Y, void* U, void* V, int width, int height,
+                             int stride, int cstride, int sz, int csuby)   /* vfgs_main.c:664-682 */
+{
+	uint8_t *py = (uint8_t*)Y, *pu = (uint8_t*)U, *pv = (uint8_t*)V;
+	for (int y = 0; y < height; y++)
+	{
+		fn(py, pu, pv, y, width);
+		py += (size_t)stride * sz;
+		if ((y & 1) || csuby == 1)
+		{
+			pu += (size_t)cstride * sz;
+			pv += (size_t)cstride * sz;
+		}
+	}
+}
+
 /* ---- synthetic input ------------------------------------------------------ */
 
 uint32_t vfgs_oracle_lcg_fill(uint32_t x, void* dst, uint64_t nsamples, int depth) /* SURVEY.md Appendix B */

@@ -169,6 +169,29 @@ def test_frame_parts_equal_whole_frame_and_keep_seeds(hip):
         assert d.download().equal_all(wnt)
 
 
+def test_out_of_place_equals_in_place_and_keeps_source(hip):
+    from gpu_util import DevFrame, stream_ptr
+    for name in ("fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_ff_test6_8_422"):
+        ora, (depth, sx, sy) = program(hip, name)
+        f, _ = T.lcg_frames(456, 304, depth, sx, sy, 1)
+        f = f[0]
+        want = f.copy()
+        ora.add_grain_frame(want)
+        src, dst = DevFrame(f), DevFrame(f)
+        for t in (dst.Y, dst.U, dst.V):
+            t.fill_(0x5a)
+        hip.add_grain_copy_dev(*src.ptrs(), *dst.ptrs(), f.width, f.height, 0, f.height, f.stride, f.cstride, 1, 0, 0, stream_ptr())
+        assert src.download().equal_all(f)                    # source untouched
+        got = dst.download()
+        assert got.equal_picture(want)
+        # whole 16-sample blocks are written (quirk 7); everything else in dst stays as it was
+        nb = (f.width + 15) // 16 * 16
+        assert np.array_equal(got.Y[:f.height, :nb], want.Y[:f.height, :nb])
+        assert (got.Y[:f.height, nb:].view(np.uint8) == 0x5a).all()
+        assert (got.Y[f.height:].view(np.uint8) == 0x5a).all()
+        assert hip.seed_state() == ora.seed_state()
+
+
 def test_zero_scale_is_clip_only_at_full_size(hip):
     """Size-independent property on a 4320p frame: all-zero scale LUTs -> out = clip(in)
     (quirk 1: 10-bit full range clips at 1020), and a second pass changes nothing."""

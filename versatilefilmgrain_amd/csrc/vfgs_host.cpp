@@ -302,7 +302,9 @@ void build_tables(const State& s, std::vector<uint8_t>& img)
 		{
 			const int slot = s.plut[c][i] >> 4;   // vfgs_hw.c:212
 			const uint32_t sel = slot < vfgs::kSlots ? (uint32_t)slot : 0x0cu;  // slot 8: the reference's all-zero bank
-			lut[c * 256 + i] = sel | ((uint32_t)s.slut[c][i] << 16);
+			const int sc = s.slut[c][i];
+			lut[c * 512 + i] = (sel << 24) | (uint32_t)(uint16_t)(int16_t)sc;          // +scale table
+			lut[c * 512 + 256 + i] = (sel << 24) | (uint32_t)(uint16_t)(int16_t)(-sc); // -scale table
 		}
 }
 
@@ -386,22 +388,34 @@ int check_geometry(const State& s, const void* dY, const void* dU, const void* d
 }
 
 // Core: launch the kernel over `nframes` frames, lines [part_y, part_y+part_h) of each.
-int run_device(void* dY, void* dU, void* dV, unsigned width, unsigned frame_y, unsigned frame_h,
-               unsigned part_y, unsigned part_h, unsigned stride, unsigned cstride, unsigned nframes,
-               uint64_t ypitch, uint64_t cpitch, hipStream_t stream)
+int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV, unsigned width,
+               unsigned frame_y, unsigned frame_h, unsigned part_y, unsigned part_h, unsigned stride, unsigned cstride,
+               unsigned nframes, uint64_t ypitch, uint64_t cpitch, hipStream_t stream)
 {
 	State& s = S();
 	if (int e = ensure_init(-1)) return e;
 	if (int e = check_geometry(s, dY, dU, dV, width, stride, cstride)) return e;
+	if (int e = check_geometry(s, sY, sU, sV, width, stride, cstride)) return e;
 	if (part_h == 0 || nframes == 0) return 0;
 
 	const unsigned nblk = (width + 15) / 16;
+	const unsigned sz = s.bs ? 2 : 1;
+	const uint64_t crows = (uint64_t)(part_y + part_h - 1) / s.csuby - part_y / s.csuby + 1;
+	const uint64_t yext = (uint64_t)part_h * stride * sz, cext = crows * cstride * sz;
+	if (yext >= 0x80000000ull || cext >= 0x80000000ull)
+		return fail(15, "a plane stripe of %llu bytes exceeds the 2 GiB buffer window", (unsigned long long)yext);
 	KernelArgs a{};
-	a.Y = (uint8_t*)dY; a.U = (uint8_t*)dU; a.V = (uint8_t*)dV;
+	a.Y = (const uint8_t*)sY; a.U = (const uint8_t*)sU; a.V = (const uint8_t*)sV;
+	a.dY = (uint8_t*)dY; a.dU = (uint8_t*)dU; a.dV = (uint8_t*)dV;
+	a.y_extent = (uint32_t)yext; a.c_extent = (uint32_t)cext;
 	a.y_frame_pitch = ypitch; a.c_frame_pitch = cpitch;
 	a.y0 = (int)part_y; a.nlines = (int)part_h;
 	a.nblk = (int)nblk;
-	a.ntx = (int)((16 * nblk + 8 + vfgs::kTilePx - 1) / vfgs::kTilePx);
+	// units of 8 samples per row incl. the (invalid) one left of the picture: 2*nblk + 1; split
+	// into the fewest tiles of at most 64 units, all of the same even length (vfgs_kernel.hip)
+	const unsigned tunits = 2 * nblk + 1;
+	a.ntx = (int)((tunits + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits);
+	a.upt = (int)(2 * ((tunits + 2 * a.ntx - 1) / (2 * a.ntx)));
 	a.nbr = (int)(((part_y + part_h - 1) >> 4) - (part_y >> 4) + 1);
 	a.stride = (int)stride; a.cstride = (int)cstride;
 	a.nframes = (int)nframes;
@@ -430,8 +444,11 @@ int run_device(void* dY, void* dU, void* dV, unsigned width, unsigned frame_y, u
 	a.up_bit0 = (uint32_t)(first_up - s.lfsr.base_bit());
 	a.frame_bit_step = nframes > 1 ? (uint32_t)(second_cur - first_cur) : 0;
 
-	const long total = (long)a.nbr * a.ntx * a.nframes;
-	const int grid = (int)std::min<long>((total + vfgs::kWavesPerWG - 1) / vfgs::kWavesPerWG, s.cu_count);
+	const long total = (long)a.nbr * 4 * a.ntx * a.nframes;
+	if (total > 0x7fffffffL) return fail(14, "launch too large");
+	a.nitems = (int)total;
+	// persistent workgroups: at most kWGPerCU per CU, each loops over the items round-robin
+	const int grid = (int)std::min<long>((total + vfgs::kWavesPerWG - 1) / vfgs::kWavesPerWG, (long)s.cu_count * vfgs::kWGPerCU);
 	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, grid, stream));
 	return 0;
 }
@@ -466,7 +483,7 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 		}
 		HIP_TRY(hipMemcpy2DAsync(s.stage[i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, s.own_stream));
 	}
-	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], width, y, height, y, height,
+	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], s.stage[0], s.stage[1], s.stage[2], width, y, height, y, height,
 	                       dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, s.own_stream))
 		return e;
 	for (int i = 0; i < 3; i++)
@@ -617,14 +634,14 @@ int vfgs_hip_add_grain_stripe_dev(void* dY, void* dU, void* dV, unsigned y, unsi
                                   unsigned stride, unsigned cstride, void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
-	return run_device(dY, dU, dV, width, y, height, y, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+	return run_device(dY, dU, dV, dY, dU, dV, width, y, height, y, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
 }
 
 int vfgs_hip_add_grain_frame_dev(void* dY, void* dU, void* dV, unsigned width, unsigned height,
                                  unsigned stride, unsigned cstride, void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
-	return run_device(dY, dU, dV, width, 0, height, 0, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+	return run_device(dY, dU, dV, dY, dU, dV, width, 0, height, 0, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
 }
 
 int vfgs_hip_add_grain_frame_part_dev(void* dY, void* dU, void* dV, unsigned width, unsigned frame_height,
@@ -633,7 +650,7 @@ int vfgs_hip_add_grain_frame_part_dev(void* dY, void* dU, void* dV, unsigned wid
 	std::lock_guard<std::mutex> g(g_mu);
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
 	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
-	return run_device(dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
 }
 
 int vfgs_hip_add_grain_frames_dev(void* dY, void* dU, void* dV, unsigned width, unsigned height, unsigned stride,
@@ -642,7 +659,33 @@ int vfgs_hip_add_grain_frames_dev(void* dY, void* dU, void* dV, unsigned width, 
 {
 	std::lock_guard<std::mutex> g(g_mu);
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
-	return run_device(dY, dU, dV, width, 0, height, 0, height, stride, cstride, nframes,
+	return run_device(dY, dU, dV, dY, dU, dV, width, 0, height, 0, height, stride, cstride, nframes,
+	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
+}
+
+int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned width, unsigned frame_height,
+                                       unsigned part_y, unsigned part_height, unsigned stride, unsigned cstride,
+                                       unsigned nframes, uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes,
+                                       void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
+	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
+	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
+	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
+}
+
+int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV,
+                                unsigned width, unsigned frame_height, unsigned part_y, unsigned part_height,
+                                unsigned stride, unsigned cstride, unsigned nframes,
+                                uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
+	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
+	return run_device(sY, sU, sV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
 	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
 }
 

@@ -11,13 +11,14 @@
 // window of the block row above feeds the 2-line overlap.
 //
 // Work decomposition (see DESIGN.md "kernel"):
-//   * one WAVEFRONT owns one tile = 8 grain blocks (128 luma samples) x one block row
-//     (16 luma lines) of Y and the co-located Cb/Cr samples;
-//   * every lane moves 16 bytes (10-bit) / 8 bytes (8-bit) = 8 samples per access, 16 lanes
-//     cover a 256-byte luma row segment, 4 rows per wave-instruction;
-//   * tiles are shifted by HALF A BLOCK (8 luma samples) against the block grid, so every
+//   * one WAVEFRONT owns one work item = up to 32 grain blocks (<= 512 luma samples) x 4 luma
+//     lines of Y, plus the co-located Cb/Cr samples; each grain block is served by a fixed
+//     lane pair of that wavefront, which derives the block's LFSR window in registers;
+//   * every lane moves 16 bytes (10-bit) / 8 bytes (8-bit) = 8 samples per access, so one
+//     wave-instruction reads or writes one contiguous <= 1 KiB row segment;
+//   * items are shifted by HALF A BLOCK (8 luma samples) against the block grid, so every
 //     block edge -- the only place where a sample depends on its horizontal neighbours --
-//     lies strictly inside a tile: no halo, no inter-wave exchange, in-place is race free;
+//     lies strictly inside an item: no halo, no inter-wave exchange, in-place is race free;
 //   * pattern banks (slot-interleaved) and LUTs are staged once per workgroup in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,6 +34,11 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------
 // small device helpers
+//
+// Issue rates measured on MI355X (tools/valu_rate.hip): plain VOP2 integer ops (add, and,
+// shifts) take 2 cycles per wave-instruction; VOP3-only, packed-16, SDWA and DPP forms
+// (v_perm_b32, v_mad_*, v_pk_*, v_bfe_*, v_add3) take 4.  The per-sample sequence below is
+// chosen against those prices (DESIGN.md "instruction budget").
 
 __device__ __forceinline__ uint32_t stream_window(const uint32_t* __restrict__ s, uint32_t bit)
 {
@@ -63,19 +69,26 @@ __device__ __forceinline__ BlockParam block_param(uint32_t v, uint32_t bank_off)
 	return r;
 }
 
-// One sample's pattern value out of its 8-byte slot group {hi,lo}, slot chosen by the low
-// byte of the LUT entry (0..7, or 0x0c = constant 0).
+// One sample's pattern value out of its 8-byte slot group {hi,lo}: the LUT entry's top byte is
+// the v_perm_b32 selector (slot 0..7, or 0x0c = constant 0) for result byte 3; the arithmetic
+// shift then sign-extends it (the other three result bytes are don't-care).
 __device__ __forceinline__ int pick_slot(uint32_t hi, uint32_t lo, uint32_t lut_entry)
 {
-	return (int)(int8_t)__builtin_amdgcn_perm(hi, lo, lut_entry);
+	return (int)__builtin_amdgcn_perm(hi, lo, lut_entry) >> 24;
 }
 
-// 24-bit multiplies are full rate; the 32-bit v_mul_lo_u32 / v_mad_u64_u32 the compiler would
-// otherwise pick are quarter rate.  Every product here fits easily (|pattern| < 2^9, scale < 2^8,
-// weights < 2^6).
+// 24-bit multiplies: the compiler would otherwise pick 32-bit multiplies for these.
 __device__ __forceinline__ int mad24(int a, int b, int c)
 {
 	return __mul24(a, b) + c;
+}
+
+// x.i16[0] * y.i16[0] + c  (one VOP3 instruction; y is a LUT entry whose low half is the signed scale)
+__device__ __forceinline__ int mad_i16(int x, uint32_t y, int c)
+{
+	int r;
+	asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(c));
+	return r;
 }
 
 __device__ __forceinline__ int swap_lane_pairs(int v)
@@ -84,84 +97,130 @@ __device__ __forceinline__ int swap_lane_pairs(int v)
 	return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
 }
 
-template <int BYTES, int ALIGN>
-__device__ __forceinline__ void gload(const uint8_t* p, uint32_t* dst)
+// Global memory goes through raw buffer instructions: the row base is a wave-uniform scalar
+// offset, the lane supplies the byte offset inside the row, and a lane that must not touch
+// memory supplies kOOB, which the hardware range check (offset >= num_records) turns into
+// "load returns 0 / store is dropped".  No exec-mask branches around loads and stores.
+constexpr uint32_t kOOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const uint8_t* base, uint32_t row_bytes)
 {
-	p = (const uint8_t*)__builtin_assume_aligned(p, ALIGN);
-	__builtin_memcpy(dst, p, BYTES);
+	return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, row_bytes, 0x00020000);
 }
 
-template <int BYTES, int ALIGN>
-__device__ __forceinline__ void gstore(uint8_t* p, const uint32_t* src)
-{
-	p = (uint8_t*)__builtin_assume_aligned(p, ALIGN);
-	__builtin_memcpy(p, src, BYTES);
-}
-
-// A lane's 8 consecutive samples of one row, as two independently valid halves of 4.
+// A lane's 8 consecutive samples of one row, as two independently addressable halves of 4
+// (SPLIT: the halves belong to different grain blocks and can be valid independently).
 // DEPTH 10: 16 bytes in memory, kept as 4 dwords of two uint16 each.
 // DEPTH  8:  8 bytes in memory, widened to the same 4 x (2 x uint16) form.
-template <int DEPTH, int ALIGN>
-__device__ __forceinline__ void load_unit(const uint8_t* p, bool v0, bool v1, uint32_t (&w)[4])
+template <int DEPTH, bool SPLIT>
+__device__ __forceinline__ void load_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t v1, uint32_t soff, uint32_t (&w)[4])
 {
-	w[0] = w[1] = w[2] = w[3] = 0;
 	if (DEPTH > 8)
 	{
-		if (v0 && v1) gload<16, ALIGN>(p, w);
-		else if (v0)  gload<8, ALIGN>(p, w);
-		else if (v1)  gload<8, ALIGN>(p + 8, w + 2);
+		if (!SPLIT)
+		{
+			const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, v0, soff, 0);
+			w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+		}
+		else
+		{
+			const u32x2 t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, v0, soff, 0);
+			const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, v1, soff, 0);
+			w[0] = t0.x; w[1] = t0.y; w[2] = t1.x; w[3] = t1.y;
+		}
 	}
 	else
 	{
-		uint32_t r[2] = {0, 0};
-		if (v0 && v1) gload<8, ALIGN>(p, r);
-		else if (v0)  gload<4, ALIGN>(p, r);
-		else if (v1)  gload<4, ALIGN>(p + 4, r + 1);
-		w[0] = __builtin_amdgcn_perm(0, r[0], 0x0c010c00);
-		w[1] = __builtin_amdgcn_perm(0, r[0], 0x0c030c02);
-		w[2] = __builtin_amdgcn_perm(0, r[1], 0x0c010c00);
-		w[3] = __builtin_amdgcn_perm(0, r[1], 0x0c030c02);
+		uint32_t r0, r1;
+		if (!SPLIT)
+		{
+			const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, v0, soff, 0);
+			r0 = t.x; r1 = t.y;
+		}
+		else
+		{
+			r0 = __builtin_amdgcn_raw_buffer_load_b32(rs, v0, soff, 0);
+			r1 = __builtin_amdgcn_raw_buffer_load_b32(rs, v1, soff, 0);
+		}
+		w[0] = __builtin_amdgcn_perm(0, r0, 0x0c010c00);
+		w[1] = __builtin_amdgcn_perm(0, r0, 0x0c030c02);
+		w[2] = __builtin_amdgcn_perm(0, r1, 0x0c010c00);
+		w[3] = __builtin_amdgcn_perm(0, r1, 0x0c030c02);
 	}
 }
 
-template <int DEPTH, int ALIGN>
-__device__ __forceinline__ void store_unit(uint8_t* p, bool v0, bool v1, const uint32_t (&w)[4])
+template <int DEPTH, bool SPLIT>
+__device__ __forceinline__ void store_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t v1, uint32_t soff, const uint32_t (&w)[4])
 {
+#if VFGS_ABLATE == 5   // (almost) never store: keeps the math alive, drops the write traffic
+	if (!(w[0] == 0x12345678u && w[3] == 0x9abcdef0u)) return;
+#endif
 	if (DEPTH > 8)
 	{
-		if (v0 && v1) gstore<16, ALIGN>(p, w);
-		else if (v0)  gstore<8, ALIGN>(p, w);
-		else if (v1)  gstore<8, ALIGN>(p + 8, w + 2);
+		if (!SPLIT)
+		{
+			const u32x4 t = {w[0], w[1], w[2], w[3]};
+			__builtin_amdgcn_raw_buffer_store_b128(t, rs, v0, soff, 0);
+		}
+		else
+		{
+			const u32x2 t0 = {w[0], w[1]}, t1 = {w[2], w[3]};
+			__builtin_amdgcn_raw_buffer_store_b64(t0, rs, v0, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b64(t1, rs, v1, soff, 0);
+		}
 	}
 	else
 	{
-		uint32_t r[2];
-		r[0] = __builtin_amdgcn_perm(w[1], w[0], 0x06040200);
-		r[1] = __builtin_amdgcn_perm(w[3], w[2], 0x06040200);
-		if (v0 && v1) gstore<8, ALIGN>(p, r);
-		else if (v0)  gstore<4, ALIGN>(p, r);
-		else if (v1)  gstore<4, ALIGN>(p + 4, r + 1);
+		const uint32_t r0 = __builtin_amdgcn_perm(w[1], w[0], 0x06040200);
+		const uint32_t r1 = __builtin_amdgcn_perm(w[3], w[2], 0x06040200);
+		if (!SPLIT)
+		{
+			const u32x2 t = {r0, r1};
+			__builtin_amdgcn_raw_buffer_store_b64(t, rs, v0, soff, 0);
+		}
+		else
+		{
+			__builtin_amdgcn_raw_buffer_store_b32(r0, rs, v0, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(r1, rs, v1, soff, 0);
+		}
 	}
 }
 
 // ---------------------------------------------------------------------------------------
 // The per-lane grain pipeline for 8 samples of one row.
 //
-//   w        in/out: samples, 4 x (2 x uint16)
-//   lut      LDS byte offset of this component's 256-entry LUT
-//   a0,a1    LDS byte offsets of the pattern data of samples 0-3 / 4-7 (current block row)
-//   m0,m1    multipliers of those pattern values: sign (x overlap weight if OVERLAP)
-//   u0,u1,n0,n1  same for the block row above (OVERLAP only)
-//   EDGE16   true : block edge between this lane and its pair lane (16-sample blocks);
-//                   `odd` lanes hold the right-hand block's first sample in slot 0,
-//                   even lanes the left-hand block's last sample in slot 7
-//            false: block edge between samples 3 and 4 of this lane (8-sample blocks)
+//   w          in/out: samples, 4 x (2 x uint16)
+//   lut0,lut1  LDS byte offsets of the 256-entry LUT used by samples 0-3 / 4-7
+//   a0,a1      LDS byte offsets of the pattern data of samples 0-3 / 4-7 (current block row)
+//
+// Two forms of the same arithmetic (vfgs_hw.c:211-229, 250-267):
+//
+// OVERLAP = true (the two lines under a block-row boundary): pattern values are blended as
+//   P = (Pcur * m + Pup * n + 16) >> 5 with m = sign_cur * w_cur, n = sign_up * w_up, so P is
+//   the signed grain; lut0/lut1 are the +scale tables; rel = 1, c0 = c1 = 2.
+//   Lanes on other lines of the same access carry (m, n) = (32 * sign, 0): (32 P + 16) >> 5 == P.
+//
+// OVERLAP = false: the block sign s is folded into the scale instead of the pattern value:
+//   lut0/lut1 point at the table of sign * scale, P~ = s * P is used unsigned-by-sign, and
+//   round(scale * P, shift) == (s*scale) * P~ ... exactly (s*s == 1).  The 3-tap edge filter
+//   F = (l1 + 3 l0 + r0 + 2) >> 2 on true values becomes, in the P~ domain of the lane whose
+//   sample is filtered,  F~ = (a~ + 3 b~ + rel * c~ + (s > 0 ? 2 : 1)) >> 2  with rel = s * s'
+//   the relative sign of the two blocks: for s = -1, -((-A + 2) >> 2) == (A + 1) >> 2.
+//
+//   EDGE16 true : block edge between this lane and its pair lane (16-sample blocks); `first`
+//                 lanes hold the right-hand block's first sample in slot 0, their partners
+//                 the left-hand block's last sample in slot 7
+//          false: block edge between samples 3 and 4 of this lane (8-sample blocks)
 template <int DEPTH, bool OVERLAP, bool EDGE16>
-__device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4], uint32_t lut,
+__device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4], uint32_t lut0, uint32_t lut1,
                                             uint32_t a0, uint32_t a1, int m0, int m1,
                                             uint32_t u0, uint32_t u1, int n0, int n1,
-                                            bool edge_on, bool odd, int scale_shift, uint32_t lo2, uint32_t hi2)
+                                            bool edge_on, bool first, int rel, int c0, int c1,
+                                            int scale_shift, int half, uint32_t lo2, uint32_t hi2)
 {
+#if VFGS_ABLATE == 1
+	return;
+#endif
 	uint32_t e[8];
 	int P[8];
 
@@ -169,67 +228,60 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 #pragma unroll
 	for (int k = 0; k < 4; k++)
 	{
-		uint32_t idx = (DEPTH > 8) ? (w[k] & 0x03fc03fcu) : ((w[k] & 0x00ff00ffu) << 2);
+		const uint32_t idx = (DEPTH > 8) ? (w[k] & 0x03fc03fcu) : ((w[k] & 0x00ff00ffu) << 2);
+		const uint32_t lut = k < 2 ? lut0 : lut1;
 		e[2 * k]     = *(const uint32_t*)(lds + lut + (idx & 0xffffu));
 		e[2 * k + 1] = *(const uint32_t*)(lds + lut + (idx >> 16));
 	}
 
 	// pattern fetch: 4 samples x 8 slots = 32 bytes per half
 	{
-		u32x4 c0 = *(const u32x4*)(lds + a0), c1 = *(const u32x4*)(lds + a0 + 16);
-		u32x4 c2 = *(const u32x4*)(lds + a1), c3 = *(const u32x4*)(lds + a1 + 16);
-		P[0] = pick_slot(c0.y, c0.x, e[0]); P[1] = pick_slot(c0.w, c0.z, e[1]);
-		P[2] = pick_slot(c1.y, c1.x, e[2]); P[3] = pick_slot(c1.w, c1.z, e[3]);
-		P[4] = pick_slot(c2.y, c2.x, e[4]); P[5] = pick_slot(c2.w, c2.z, e[5]);
-		P[6] = pick_slot(c3.y, c3.x, e[6]); P[7] = pick_slot(c3.w, c3.z, e[7]);
+		const u32x4 c0_ = *(const u32x4*)(lds + a0), c1_ = *(const u32x4*)(lds + a0 + 16);
+		const u32x4 c2_ = *(const u32x4*)(lds + a1), c3_ = *(const u32x4*)(lds + a1 + 16);
+		P[0] = pick_slot(c0_.y, c0_.x, e[0]); P[1] = pick_slot(c0_.w, c0_.z, e[1]);
+		P[2] = pick_slot(c1_.y, c1_.x, e[2]); P[3] = pick_slot(c1_.w, c1_.z, e[3]);
+		P[4] = pick_slot(c2_.y, c2_.x, e[4]); P[5] = pick_slot(c2_.w, c2_.z, e[5]);
+		P[6] = pick_slot(c3_.y, c3_.x, e[6]); P[7] = pick_slot(c3_.w, c3_.z, e[7]);
 	}
 	if (OVERLAP)
 	{
-		// vfgs_hw.c:223-229; lanes outside the two overlap lines carry weights (32, 0): (32 P + 16) >> 5 == P
-		u32x4 c0 = *(const u32x4*)(lds + u0), c1 = *(const u32x4*)(lds + u0 + 16);
-		u32x4 c2 = *(const u32x4*)(lds + u1), c3 = *(const u32x4*)(lds + u1 + 16);
+		const u32x4 c0_ = *(const u32x4*)(lds + u0), c1_ = *(const u32x4*)(lds + u0 + 16);
+		const u32x4 c2_ = *(const u32x4*)(lds + u1), c3_ = *(const u32x4*)(lds + u1 + 16);
 		int Q[8];
-		Q[0] = pick_slot(c0.y, c0.x, e[0]); Q[1] = pick_slot(c0.w, c0.z, e[1]);
-		Q[2] = pick_slot(c1.y, c1.x, e[2]); Q[3] = pick_slot(c1.w, c1.z, e[3]);
-		Q[4] = pick_slot(c2.y, c2.x, e[4]); Q[5] = pick_slot(c2.w, c2.z, e[5]);
-		Q[6] = pick_slot(c3.y, c3.x, e[6]); Q[7] = pick_slot(c3.w, c3.z, e[7]);
+		Q[0] = pick_slot(c0_.y, c0_.x, e[0]); Q[1] = pick_slot(c0_.w, c0_.z, e[1]);
+		Q[2] = pick_slot(c1_.y, c1_.x, e[2]); Q[3] = pick_slot(c1_.w, c1_.z, e[3]);
+		Q[4] = pick_slot(c2_.y, c2_.x, e[4]); Q[5] = pick_slot(c2_.w, c2_.z, e[5]);
+		Q[6] = pick_slot(c3_.y, c3_.x, e[6]); Q[7] = pick_slot(c3_.w, c3_.z, e[7]);
 #pragma unroll
 		for (int k = 0; k < 8; k++)
 			P[k] = mad24(Q[k], k < 4 ? n0 : n1, mad24(P[k], k < 4 ? m0 : m1, 16)) >> 5;
-	}
-	else
-	{
-#pragma unroll
-		for (int k = 0; k < 8; k++)
-			P[k] = __mul24(P[k], k < 4 ? m0 : m1);
 	}
 
 	// 3-tap filter across the block edge (vfgs_hw.c:250-259), on unfiltered neighbours
 	if (EDGE16)
 	{
-		int mine = odd ? P[0] : P[7];
-		int inner = odd ? P[1] : P[6];
-		int theirs = swap_lane_pairs(mine);
-		int f = (inner + 3 * mine + theirs + 2) >> 2;
+		const int mine = first ? P[0] : P[7];
+		const int inner = first ? P[1] : P[6];
+		const int theirs = swap_lane_pairs(mine);
+		int f = (inner + 3 * mine + __mul24(rel, theirs) + c0) >> 2;
 		f = edge_on ? f : mine;
-		P[0] = odd ? f : P[0];
-		P[7] = odd ? P[7] : f;
+		P[0] = first ? f : P[0];
+		P[7] = first ? P[7] : f;
 	}
 	else
 	{
-		int l1 = P[2], l0 = P[3], r0 = P[4], r1 = P[5];
-		P[3] = edge_on ? ((l1 + 3 * l0 + r0 + 2) >> 2) : l0;
-		P[4] = edge_on ? ((l0 + 3 * r0 + r1 + 2) >> 2) : r0;
+		const int l1 = P[2], l0 = P[3], r0 = P[4], r1 = P[5];
+		P[3] = edge_on ? ((l1 + 3 * l0 + __mul24(rel, r0) + c0) >> 2) : l0;
+		P[4] = edge_on ? ((__mul24(rel, l0) + 3 * r0 + r1 + c1) >> 2) : r0;
 	}
 
 	// scale, add, clip (vfgs_hw.c:263-267)
-	const int half = 1 << (scale_shift - 1);
 #pragma unroll
 	for (int k = 0; k < 4; k++)
 	{
-		int g0 = mad24(P[2 * k], (int)(e[2 * k] >> 16), half) >> scale_shift;
-		int g1 = mad24(P[2 * k + 1], (int)(e[2 * k + 1] >> 16), half) >> scale_shift;
-		uint32_t gp = __builtin_amdgcn_perm((uint32_t)g1, (uint32_t)g0, 0x05040100);
+		const int g0 = mad_i16(P[2 * k], e[2 * k], half) >> scale_shift;
+		const int g1 = mad_i16(P[2 * k + 1], e[2 * k + 1], half) >> scale_shift;
+		const uint32_t gp = __builtin_amdgcn_perm((uint32_t)g1, (uint32_t)g0, 0x05040100);
 		uint32_t v = w[k];
 		if (DEPTH > 8)  // a 16-bit container may hold anything: keep the add inside int16 (result is clipped anyway)
 			v = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, v), __builtin_bit_cast(u16x2, 0x70007000u)));
@@ -241,200 +293,326 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 }
 
 // ---------------------------------------------------------------------------------------
-// One plane of one tile.
+// Geometry of one work item along x.
 //
-//   BW    block width in samples of this plane (16: luma and 4:4:4 chroma; 8: subsampled chroma)
-//   SUBY  vertical subsampling of this plane
-//   RS    bank row stride
-// Lane geometry: LPR lanes per row, RPL rows per wave-access, NLOAD accesses per block row.
-template <int DEPTH, int COMP, int BW, int SUBX, int SUBY, int RS>
-struct PlaneTile {
-	static constexpr int SZ = DEPTH > 8 ? 2 : 1;
-	static constexpr int LPR = (kTilePx / SUBX) / 8;     // 16 or 8
-	static constexpr int RPL = 64 / LPR;                 // 4 or 8
-	static constexpr int ROWS = 16 / SUBY;               // plane rows per block row
-	static constexpr int NLOAD = ROWS / RPL;
-	static constexpr int ALIGN = (BW == 16) ? 8 * SZ : 4 * SZ;  // half-block shift: 8 (4) samples
-	static_assert(NLOAD >= 1, "");
+// A row of nblk grain blocks is cut into "units" of 8 samples: unit j covers luma samples
+// [8j, 8j+8), j = 0 .. 2*nblk-1; even j = first half of block j/2, odd j = second half of block
+// (j-1)/2.  The pair (odd j, j+1) straddles the edge between two blocks and always stays in
+// one item: item tx owns units [tx*L - 1, tx*L - 1 + L), L even (a.upt), lane i <-> unit tx*L-1+i.
+// Subsampled chroma (8-sample blocks): one lane owns the 8 chroma samples around block edge
+// m, i.e. the second half of block m-1 and the first half of block m; 32 lanes per row.
 
-	uint32_t w[NLOAD][4];
-	bool v0[NLOAD], v1[NLOAD];
-	uint8_t* ptr[NLOAD];
-	// per-lane block data
-	BlockParam cur0, cur1, up0, up1;   // half 0 / half 1 (same block for BW == 16)
-	uint32_t half_off0, half_off1;     // byte offsets inside the bank row
-	bool edge_on, odd;
-	int rloc0;                         // plane row inside the block row for access 0
+// One work item (see "Geometry" above).  SPLIT = the item touches the left or right picture
+// edge, where a subsampled-chroma lane can own only one valid half: those items move chroma in
+// two 8-byte halves per lane, all others in one 16-byte access.
+//
+// PHASE 0 issues the item's global loads into (wy, wu, wv) and returns; PHASE 1 takes those
+// registers, computes and stores.  The kernel runs PHASE 0 of the NEXT item before PHASE 1 of
+// the current one, so every wave has its next loads in flight while it computes.
+template <int DEPTH, int CSUBX, int CSUBY, bool SPLITC, int PHASE>
+__device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds, const int item, const int lane,
+                                        uint32_t (&wy)[4][4], uint32_t (&wu)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4],
+                                        uint32_t (&wv)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4])
+{
+	using L = TableLayout<CSUBX, CSUBY>;
+	constexpr int SZ = DEPTH > 8 ? 2 : 1;
+	constexpr int CBW = 16 / CSUBX;               // chroma block width in samples
+	constexpr int CROWS = 4 / CSUBY;              // chroma rows per item (4 luma lines)
+	constexpr int CRPL = (CBW == 16) ? 1 : 2;     // chroma rows per wave access
+	constexpr int CNL = CROWS / CRPL;             // chroma accesses per plane per item
+	constexpr uint32_t LUTY = L::LUT_OFF, LUTU = L::LUT_OFF + 2048, LUTV = L::LUT_OFF + 4096;   // [+scale | -scale] each
 
-	// issue the global loads of this plane
-	__device__ __forceinline__ void issue(const KernelArgs& a, uint8_t* plane, int pstride, int tx, int R, int lane)
+	constexpr bool SPLIT = SPLITC && (CBW != 16);
+	const int nunits = 2 * a.nblk;
+	const int last = a.nblk - 1;
+	const int half = 1 << (a.scale_shift - 1);
+	const uint32_t ylo2 = (uint32_t)a.ylo * 0x10001u, yhi2 = (uint32_t)a.yhi * 0x10001u;
+	const uint32_t clo2 = (uint32_t)a.clo * 0x10001u, chi2 = (uint32_t)a.chi * 0x10001u;
+
+
+	// item -> (frame f, block row k of the stripe, line quad p, tile tx); tx fastest
+	int t = item;
+	const int tx = t % a.ntx; t /= a.ntx;
+	const int p = t & 3;      t >>= 2;
+	const int k = t % a.nbr;
+	const int f = t / a.nbr;
+	const int R = (a.y0 >> 4) + k;                // absolute block row (y >> 4)
+	const bool has_up = (R > 0) && (p == 0);      // lines j = 0, 1 of a block row below the first (vfgs_hw.c:175,180)
+
+	// whole item outside the stripe (only for stripes that are not multiples of 16 lines)?
+	if (PHASE == 1 && (16 * R + 4 * p + 3 < a.y0 || 16 * R + 4 * p >= a.y0 + a.nlines))
+		return;
+
+	// one descriptor per plane of this frame's stripe; num_records = its exact extent, so the
+	// hardware bounds-checks every access of the item
+	const uint32_t yrow = (uint32_t)(a.stride * SZ), crow = (uint32_t)(a.cstride * SZ);
+	const __amdgpu_buffer_rsrc_t sY = make_rsrc(a.Y + (uint64_t)f * a.y_frame_pitch, a.y_extent);
+	const __amdgpu_buffer_rsrc_t sU = make_rsrc(a.U + (uint64_t)f * a.c_frame_pitch, a.c_extent);
+	const __amdgpu_buffer_rsrc_t sV = make_rsrc(a.V + (uint64_t)f * a.c_frame_pitch, a.c_extent);
+	const __amdgpu_buffer_rsrc_t dY = make_rsrc(a.dY + (uint64_t)f * a.y_frame_pitch, a.y_extent);
+	const __amdgpu_buffer_rsrc_t dU = make_rsrc(a.dU + (uint64_t)f * a.c_frame_pitch, a.c_extent);
+	const __amdgpu_buffer_rsrc_t dV = make_rsrc(a.dV + (uint64_t)f * a.c_frame_pitch, a.c_extent);
+
+	const int j0 = tx * a.upt - 1;                // first unit of this item
+
+	// ---- issue every global load of the item first ------------------------------------
+	// luma: one row per access
+	const int ju = j0 + lane;
+	const bool l_ok = (lane < a.upt) && (ju >= 0) && (ju < nunits);
+	const bool l_first = !(ju & 1);               // first half of its block
+	uint32_t voy[4];
+#pragma unroll
+	for (int r = 0; r < 4; r++)
 	{
-		const int u = lane & (LPR - 1);
-		rloc0 = lane / LPR;
-		int bl, br;        // blocks left / right of the edge this lane (pair) straddles
-		bool ok0, ok1;
-		int x0;            // first sample of this lane, plane coordinates
-		if (BW == 16)
+		const int yabs = 16 * R + 4 * p + r;
+		const bool rok = (yabs >= a.y0) && (yabs < a.y0 + a.nlines);          // wave-uniform
+		// a line outside the stripe is computed but neither read nor written (all lanes out of range)
+		voy[r] = (rok && l_ok) ? (uint32_t)(yabs - a.y0) * yrow + (uint32_t)(8 * ju * SZ) : kOOB;
+		if (PHASE == 0) load_unit<DEPTH, false>(sY, voy[r], 0, 0, wy[r]);
+	}
+	// chroma
+	uint32_t cv0[CNL], cv1[CNL];
+	int crl[CNL];                                  // chroma row inside the block row, per access
+	int cm;                                        // CBW == 8: block edge index m; CBW == 16: unit index
+	bool c_first = false;
+	{
+		bool h0, h1;
+		int xc0;
+		if (CBW == 16)
 		{
-			const int m = u >> 1;
-			odd = u & 1;
-			bl = 8 * tx - 1 + m;
-			br = bl + 1;
-			const int blk = odd ? br : bl;
-			ok0 = ok1 = (blk >= 0) && (blk < a.nblk);
-			x0 = 16 * blk + (odd ? 0 : 8);
+			cm = ju;
+			h0 = h1 = l_ok;
+			c_first = l_first;
+			xc0 = 8 * ju;
 		}
 		else
 		{
-			odd = false;
-			bl = 8 * tx - 1 + u;
-			br = bl + 1;
-			ok0 = (bl >= 0) && (bl < a.nblk);
-			ok1 = (br >= 0) && (br < a.nblk);
-			x0 = 8 * bl + 4;
+			const int cu = lane & 31;
+			cm = (j0 + 1) / 2 + cu;
+			const bool in = cu < a.upt / 2;
+			h0 = in && (cm - 1 >= 0) && (cm - 1 <= last);
+			h1 = in && (cm <= last);
+			xc0 = 8 * cm - 4;
 		}
-		edge_on = (bl >= 0) && (br < a.nblk);
 #pragma unroll
-		for (int q = 0; q < NLOAD; q++)
+		for (int c = 0; c < CNL; c++)
 		{
-			const int rloc = q * RPL + rloc0;
-			const int yabs = (R * ROWS + rloc) * SUBY;   // luma line this plane row belongs to
+			crl[c] = CROWS * p + CRPL * c + ((CBW == 16) ? 0 : (lane >> 5));
+			const int prow = R * (16 / CSUBY) + crl[c];          // absolute chroma row
+			const int yabs = prow * CSUBY;
 			const bool rok = (yabs >= a.y0) && (yabs < a.y0 + a.nlines);
-			v0[q] = rok && ok0;
-			v1[q] = rok && ok1;
-			const int prow = R * ROWS + rloc - a.y0 / SUBY;   // row relative to the stripe pointer
-			ptr[q] = plane + ((int64_t)prow * pstride + x0) * SZ;
-			load_unit<DEPTH, ALIGN>(ptr[q], v0[q], v1[q], w[q]);
-		}
-	}
-
-	// derive pattern addresses / signs from the LFSR windows of blocks bl, br
-	__device__ __forceinline__ void params(uint32_t vcur_l, uint32_t vcur_r, uint32_t vup_l, uint32_t vup_r, uint32_t bank_off)
-	{
-		if (BW == 16)
-		{
-			const uint32_t vc = odd ? vcur_r : vcur_l, vu = odd ? vup_r : vup_l;
-			cur0 = cur1 = block_param<COMP, SUBX, SUBY, RS>(vc, bank_off);
-			up0 = up1 = block_param<COMP, SUBX, SUBY, RS>(vu, bank_off);
-			half_off0 = odd ? 0 : 8 * kSlots;     // even lane: samples 8..15 of the left block
-			half_off1 = half_off0 + 4 * kSlots;
-		}
-		else
-		{
-			cur0 = block_param<COMP, SUBX, SUBY, RS>(vcur_l, bank_off);
-			cur1 = block_param<COMP, SUBX, SUBY, RS>(vcur_r, bank_off);
-			up0 = block_param<COMP, SUBX, SUBY, RS>(vup_l, bank_off);
-			up1 = block_param<COMP, SUBX, SUBY, RS>(vup_r, bank_off);
-			half_off0 = 4 * kSlots;               // samples 4..7 of the left block
-			half_off1 = 0;                        // samples 0..3 of the right block
-		}
-	}
-
-	__device__ __forceinline__ void run(const KernelArgs& a, const uint8_t* lds, uint32_t lut, int R, uint32_t lo2, uint32_t hi2)
-	{
-		const bool can_overlap = (R > 0);      // y > 15 (vfgs_hw.c:175,180)
-#pragma unroll
-		for (int q = 0; q < NLOAD; q++)
-		{
-			if (__builtin_amdgcn_ballot_w64(v0[q] || v1[q]) == 0)
-				continue;                      // wave-uniform: nothing of this access lies in the stripe
-			const int rloc = q * RPL + rloc0;
-			const uint32_t rowoff = __umul24((uint32_t)rloc, (uint32_t)RS);
-			const uint32_t a0 = cur0.addr + rowoff + half_off0;
-			const uint32_t a1 = cur1.addr + rowoff + half_off1;
-			// Only access 0 can contain the two overlap lines (j = 0, 1 <=> plane rows 0 .. 1/SUBY)
-			if (q == 0 && can_overlap)
+			const uint32_t rowb = (uint32_t)(prow - a.y0 / CSUBY) * crow;
+			cv0[c] = (rok && h0) ? rowb + (uint32_t)(xc0 * SZ) : kOOB;
+			cv1[c] = (rok && h1) ? rowb + (uint32_t)((xc0 + 4) * SZ) : kOOB;
+			if (PHASE == 0)
 			{
-				const int j = rloc * SUBY;     // y & 15
-				int wc = 32, wu = 0;
-				if (j == 0) { wc = SUBY > 1 ? 20 : 12; wu = SUBY > 1 ? 20 : 24; }
-				else if (j == 1) { wc = 24; wu = 12; }
-				const uint32_t u0 = up0.addr + ROWS * RS + rowoff + half_off0;
-				const uint32_t u1 = up1.addr + ROWS * RS + rowoff + half_off1;
-				// rows without overlap must not read past the bank: clamp their (unused) address
-				const uint32_t u0s = wu ? u0 : a0, u1s = wu ? u1 : a1;
-				grain_unit<DEPTH, true, BW == 16>(lds, w[q], lut, a0, a1,
-				                                  __mul24(cur0.sign, wc), __mul24(cur1.sign, wc),
-				                                  u0s, u1s, __mul24(up0.sign, wu), __mul24(up1.sign, wu),
-				                                  edge_on, odd, a.scale_shift, lo2, hi2);
+				load_unit<DEPTH, SPLIT>(sU, cv0[c], cv1[c], 0, wu[c]);
+				load_unit<DEPTH, SPLIT>(sV, cv0[c], cv1[c], 0, wv[c]);
+			}
+		}
+	}
+	if (PHASE == 0)
+		return;
+
+	// ---- LFSR windows -> pattern addresses and signs ------------------------------------
+	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(k * a.nblk);
+	const uint32_t up_bit = (k > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
+
+	const int yblk = min(max(ju >> 1, 0), last);
+	const uint32_t vy = stream_window(a.stream, cur_bit + yblk);
+	const BlockParam ycur = block_param<0, 1, 1, L::LRS>(vy, L::LUMA_OFF);
+	int cbl, cbr;                                  // chroma: blocks left / right of the lane's edge
+	if (CBW == 16) { cbl = cbr = yblk; }
+	else { cbl = min(max(cm - 1, 0), last); cbr = min(cm, last); }
+	const uint32_t vcl = (CBW == 16) ? vy : stream_window(a.stream, cur_bit + cbl);
+	const uint32_t vcr = (CBW == 16) ? vy : stream_window(a.stream, cur_bit + cbr);
+	const BlockParam ucur0 = block_param<1, CSUBX, CSUBY, L::CRS>(vcl, L::CHROMA_OFF);
+	const BlockParam vcur0 = block_param<2, CSUBX, CSUBY, L::CRS>(vcl, L::CHROMA_OFF);
+	BlockParam ucur1 = ucur0, vcur1 = vcur0;
+	if (CBW != 16)
+	{
+		ucur1 = block_param<1, CSUBX, CSUBY, L::CRS>(vcr, L::CHROMA_OFF);
+		vcur1 = block_param<2, CSUBX, CSUBY, L::CRS>(vcr, L::CHROMA_OFF);
+	}
+	BlockParam yup = ycur, uup0 = ucur0, uup1 = ucur1, vup0 = vcur0, vup1 = vcur1;
+	if (has_up)   // wave-uniform
+	{
+		const uint32_t wyu = stream_window(a.stream, up_bit + yblk);
+		yup = block_param<0, 1, 1, L::LRS>(wyu, L::LUMA_OFF);
+		const uint32_t wl = (CBW == 16) ? wyu : stream_window(a.stream, up_bit + cbl);
+		uup0 = uup1 = block_param<1, CSUBX, CSUBY, L::CRS>(wl, L::CHROMA_OFF);
+		vup0 = vup1 = block_param<2, CSUBX, CSUBY, L::CRS>(wl, L::CHROMA_OFF);
+		if (CBW != 16)
+		{
+			const uint32_t wr = stream_window(a.stream, up_bit + cbr);
+			uup1 = block_param<1, CSUBX, CSUBY, L::CRS>(wr, L::CHROMA_OFF);
+			vup1 = block_param<2, CSUBX, CSUBY, L::CRS>(wr, L::CHROMA_OFF);
+		}
+	}
+
+	// ---- luma rows -----------------------------------------------------------------------
+	{
+		// edge between this lane pair: left unit must exist (>= 0), right unit must exist (< nunits)
+		const int jl = l_first ? ju - 1 : ju;
+		const bool edge_on = (lane < a.upt) && (jl >= 0) && (jl + 1 < nunits);
+		const uint32_t hoff = l_first ? 0u : 8u * kSlots;
+		const uint32_t base = ycur.addr + hoff;
+		const uint32_t ubase = yup.addr + 16u * L::LRS + hoff;
+		const int rel = __mul24(ycur.sign, swap_lane_pairs(ycur.sign));    // relative sign of the two blocks at the edge
+		const uint32_t luts = LUTY + (ycur.sign < 0 ? 1024u : 0u);
+		const int cs = ycur.sign < 0 ? 1 : 2;
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+		{
+			const uint32_t rowoff = (uint32_t)(4 * p + r) * L::LRS;   // scalar
+			if (r < 2 && has_up)
+			{
+				const int wc = (r == 0) ? 12 : 24, wu_ = (r == 0) ? 24 : 12;   // vfgs_hw.c:177-183, suby == 1
+				grain_unit<DEPTH, true, true>(lds, wy[r], LUTY, LUTY, base + rowoff, base + rowoff + 4 * kSlots,
+				                              ycur.sign * wc, ycur.sign * wc,
+				                              ubase + rowoff, ubase + rowoff + 4 * kSlots, yup.sign * wu_, yup.sign * wu_,
+				                              edge_on, l_first, 1, 2, 2, a.scale_shift, half, ylo2, yhi2);
 			}
 			else
 			{
-				grain_unit<DEPTH, false, BW == 16>(lds, w[q], lut, a0, a1, cur0.sign, cur1.sign,
-				                                   0, 0, 0, 0, edge_on, odd, a.scale_shift, lo2, hi2);
+				grain_unit<DEPTH, false, true>(lds, wy[r], luts, luts, base + rowoff, base + rowoff + 4 * kSlots,
+				                               0, 0, 0, 0, 0, 0,
+				                               edge_on, l_first, rel, cs, cs, a.scale_shift, half, ylo2, yhi2);
 			}
-			store_unit<DEPTH, ALIGN>(ptr[q], v0[q], v1[q], w[q]);
+			store_unit<DEPTH, false>(dY, voy[r], 0, 0, wy[r]);
 		}
 	}
-};
 
-// ---------------------------------------------------------------------------------------
+	// ---- chroma rows ---------------------------------------------------------------------
+	{
+		bool edge_on;
+		uint32_t h0, h1;
+		int relu, relv;
+		if (CBW == 16)
+		{
+			const int jl = c_first ? ju - 1 : ju;
+			edge_on = (lane < a.upt) && (jl >= 0) && (jl + 1 < nunits);
+			h0 = c_first ? 0u : 8u * kSlots;
+			h1 = h0 + 4 * kSlots;
+			relu = __mul24(ucur0.sign, swap_lane_pairs(ucur0.sign));
+			relv = __mul24(vcur0.sign, swap_lane_pairs(vcur0.sign));
+		}
+		else
+		{
+			edge_on = ((lane & 31) < a.upt / 2) && (cm - 1 >= 0) && (cm <= last);
+			h0 = 4 * kSlots;   // samples 4..7 of the left block
+			h1 = 0;            // samples 0..3 of the right block
+			relu = __mul24(ucur0.sign, ucur1.sign);
+			relv = __mul24(vcur0.sign, vcur1.sign);
+		}
+		const uint32_t lutu0 = LUTU + (ucur0.sign < 0 ? 1024u : 0u), lutu1 = LUTU + (ucur1.sign < 0 ? 1024u : 0u);
+		const uint32_t lutv0 = LUTV + (vcur0.sign < 0 ? 1024u : 0u), lutv1 = LUTV + (vcur1.sign < 0 ? 1024u : 0u);
+		const int ru0 = ucur0.sign < 0 ? 1 : 2, ru1 = ucur1.sign < 0 ? 1 : 2;
+		const int rv0 = vcur0.sign < 0 ? 1 : 2, rv1 = vcur1.sign < 0 ? 1 : 2;
+#pragma unroll
+		for (int c = 0; c < CNL; c++)
+		{
+			const uint32_t rowoff = __umul24((uint32_t)crl[c], (uint32_t)L::CRS);
+			const uint32_t ua0 = ucur0.addr + rowoff + h0, ua1 = ucur1.addr + rowoff + h1;
+			const uint32_t va0 = vcur0.addr + rowoff + h0, va1 = vcur1.addr + rowoff + h1;
+			// only accesses whose first row is line j = row * CSUBY <= 1 of the block row can hold overlap lines
+			if (has_up && (CRPL * c * CSUBY <= 1))
+			{
+				const int jj = crl[c] * CSUBY;
+				int wc = 32, wu_ = 0;
+				if (jj == 0) { wc = CSUBY > 1 ? 20 : 12; wu_ = CSUBY > 1 ? 20 : 24; }
+				else if (jj == 1) { wc = 24; wu_ = 12; }
+				const uint32_t uoff = (16 / CSUBY) * L::CRS + rowoff;
+				// lanes without overlap must not read past the bank: point their (unused) read at the current row
+				const uint32_t uu0 = wu_ ? uup0.addr + uoff + h0 : ua0, uu1 = wu_ ? uup1.addr + uoff + h1 : ua1;
+				const uint32_t vu0 = wu_ ? vup0.addr + uoff + h0 : va0, vu1 = wu_ ? vup1.addr + uoff + h1 : va1;
+				grain_unit<DEPTH, true, CBW == 16>(lds, wu[c], LUTU, LUTU, ua0, ua1, __mul24(ucur0.sign, wc), __mul24(ucur1.sign, wc),
+				                                   uu0, uu1, __mul24(uup0.sign, wu_), __mul24(uup1.sign, wu_),
+				                                   edge_on, c_first, 1, 2, 2, a.scale_shift, half, clo2, chi2);
+				grain_unit<DEPTH, true, CBW == 16>(lds, wv[c], LUTV, LUTV, va0, va1, __mul24(vcur0.sign, wc), __mul24(vcur1.sign, wc),
+				                                   vu0, vu1, __mul24(vup0.sign, wu_), __mul24(vup1.sign, wu_),
+				                                   edge_on, c_first, 1, 2, 2, a.scale_shift, half, clo2, chi2);
+			}
+			else
+			{
+				grain_unit<DEPTH, false, CBW == 16>(lds, wu[c], lutu0, lutu1, ua0, ua1, 0, 0, 0, 0, 0, 0,
+				                                    edge_on, c_first, relu, ru0, ru1, a.scale_shift, half, clo2, chi2);
+				grain_unit<DEPTH, false, CBW == 16>(lds, wv[c], lutv0, lutv1, va0, va1, 0, 0, 0, 0, 0, 0,
+				                                    edge_on, c_first, relv, rv0, rv1, a.scale_shift, half, clo2, chi2);
+			}
+			store_unit<DEPTH, SPLIT>(dU, cv0[c], cv1[c], 0, wu[c]);
+			store_unit<DEPTH, SPLIT>(dV, cv0[c], cv1[c], 0, wv[c]);
+		}
+	}
+}
 
 template <int DEPTH, int CSUBX, int CSUBY>
-__global__ __launch_bounds__(kWavesPerWG * 64) void grain_kernel(const KernelArgs a)
+__global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4) void grain_kernel(const KernelArgs a)
 {
 	using L = TableLayout<CSUBX, CSUBY>;
-	using LumaT = PlaneTile<DEPTH, 0, 16, 1, 1, L::LRS>;
-	using CbT = PlaneTile<DEPTH, 1, 16 / CSUBX, CSUBX, CSUBY, L::CRS>;
-	using CrT = PlaneTile<DEPTH, 2, 16 / CSUBX, CSUBX, CSUBY, L::CRS>;
+	constexpr int SZ = DEPTH > 8 ? 2 : 1;
+	constexpr int CBW = 16 / CSUBX;               // chroma block width in samples
+	constexpr int CROWS = 4 / CSUBY;              // chroma rows per item (4 luma lines)
+	constexpr int CRPL = (CBW == 16) ? 1 : 2;     // chroma rows per wave access
+	constexpr int CNL = CROWS / CRPL;             // chroma accesses per plane per item
+	constexpr uint32_t LUTY = L::LUT_OFF, LUTU = L::LUT_OFF + 2048, LUTV = L::LUT_OFF + 4096;   // [+scale | -scale] each
 
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L::BYTES];
 
 	// stage banks + LUTs: global (L2 resident) -> LDS, 16 bytes per lane per step
+#if VFGS_ABLATE != 6
 	for (int i = threadIdx.x * 16; i < L::BYTES; i += kWavesPerWG * 64 * 16)
 		*(u32x4*)(lds + i) = *(const u32x4*)(a.tables + i);
 	__syncthreads();
+#endif
 
 	const int lane = threadIdx.x & 63;
-	const int wave = threadIdx.x >> 6;
-	const int tiles_per_frame = a.nbr * a.ntx;
-	const int total = tiles_per_frame * a.nframes;
-	const int row0 = a.y0 >> 4;
+	// wave-uniform by construction; telling the compiler keeps item decoding, row offsets and
+	// buffer descriptors in SGPRs (otherwise every buffer instruction gets a waterfall loop)
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	// persistent: the workgroups of one launch share the items round-robin, kWavesPerWG
+	// consecutive items (neighbouring tiles of one line quad) per workgroup and step.
+	// A lane of the first tile of a row has no block to its left; a tile whose last block edge
+	// index exceeds the last block has lanes with no block to their right: those tiles take the
+	// SPLIT form of do_item (wave-uniform test).
+	constexpr int CNL_ = (4 / CSUBY) / ((CSUBX == 1) ? 1 : 2);
+	const int step = gridDim.x * kWavesPerWG;
+	int item = blockIdx.x * kWavesPerWG + wave;
+	if (item >= a.nitems)
+		return;
+	auto is_split = [&](int it) { const int tx = it % a.ntx; return tx == 0 || (tx + 1) * (a.upt / 2) > a.nblk; };
 
-	const uint32_t ylo2 = (uint32_t)a.ylo * 0x10001u, yhi2 = (uint32_t)a.yhi * 0x10001u;
-	const uint32_t clo2 = (uint32_t)a.clo * 0x10001u, chi2 = (uint32_t)a.chi * 0x10001u;
-
-	for (int t = blockIdx.x * kWavesPerWG + wave; t < total; t += gridDim.x * kWavesPerWG)
+	uint32_t wy[4][4], wu[CNL_][4], wv[CNL_][4];
+	if (is_split(item)) do_item<DEPTH, CSUBX, CSUBY, true, 0>(a, lds, item, lane, wy, wu, wv);
+	else                do_item<DEPTH, CSUBX, CSUBY, false, 0>(a, lds, item, lane, wy, wu, wv);
+	for (;;)
 	{
-		const int f = t / tiles_per_frame;
-		const int rem = t - f * tiles_per_frame;
-		const int k = rem / a.ntx;          // block row inside the stripe
-		const int tx = rem - k * a.ntx;
-		const int R = row0 + k;             // absolute block row (y >> 4)
-
-		uint8_t* Y = a.Y + (uint64_t)f * a.y_frame_pitch;
-		uint8_t* U = a.U + (uint64_t)f * a.c_frame_pitch;
-		uint8_t* V = a.V + (uint64_t)f * a.c_frame_pitch;
-
-		LumaT ty;
-		CbT tu;
-		CrT tv;
-		ty.issue(a, Y, a.stride, tx, R, lane);
-		tu.issue(a, U, a.cstride, tx, R, lane);
-		tv.issue(a, V, a.cstride, tx, R, lane);
-
-		// LFSR windows of the blocks this lane touches, for this block row and the one above
-		const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(k * a.nblk);
-		const uint32_t up_bit = (k > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
-		const int last = a.nblk - 1;
+		const int next = item + step;
+		uint32_t ny[4][4], nu[CNL_][4], nv[CNL_][4];
+#if VFGS_PREFETCH
+		if (next < a.nitems)
 		{
-			const int m = (lane & 15) >> 1;
-			const int bl = min(max(8 * tx - 1 + m, 0), last), br = min(max(8 * tx + m, 0), last);
-			ty.params(stream_window(a.stream, cur_bit + bl), stream_window(a.stream, cur_bit + br),
-			          stream_window(a.stream, up_bit + bl), stream_window(a.stream, up_bit + br), L::LUMA_OFF);
+			if (is_split(next)) do_item<DEPTH, CSUBX, CSUBY, true, 0>(a, lds, next, lane, ny, nu, nv);
+			else                do_item<DEPTH, CSUBX, CSUBY, false, 0>(a, lds, next, lane, ny, nu, nv);
 		}
-		{
-			const int m = (CSUBX == 2) ? (lane & 7) : ((lane & 15) >> 1);
-			const int bl = min(max(8 * tx - 1 + m, 0), last), br = min(max(8 * tx + m, 0), last);
-			const uint32_t cl = stream_window(a.stream, cur_bit + bl), cr = stream_window(a.stream, cur_bit + br);
-			const uint32_t ul = stream_window(a.stream, up_bit + bl), ur = stream_window(a.stream, up_bit + br);
-			tu.params(cl, cr, ul, ur, L::CHROMA_OFF);
-			tv.params(cl, cr, ul, ur, L::CHROMA_OFF);
-		}
-
-		ty.run(a, lds, L::LUT_OFF, R, ylo2, yhi2);
-		tu.run(a, lds, L::LUT_OFF + 1024, R, clo2, chi2);
-		tv.run(a, lds, L::LUT_OFF + 2048, R, clo2, chi2);
+#endif
+		if (is_split(item)) do_item<DEPTH, CSUBX, CSUBY, true, 1>(a, lds, item, lane, wy, wu, wv);
+		else                do_item<DEPTH, CSUBX, CSUBY, false, 1>(a, lds, item, lane, wy, wu, wv);
+		if (next >= a.nitems)
+			break;
+#if !VFGS_PREFETCH
+		if (is_split(next)) do_item<DEPTH, CSUBX, CSUBY, true, 0>(a, lds, next, lane, ny, nu, nv);
+		else                do_item<DEPTH, CSUBX, CSUBY, false, 0>(a, lds, next, lane, ny, nu, nv);
+#endif
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+#pragma unroll
+			for (int q = 0; q < 4; q++) wy[r][q] = ny[r][q];
+#pragma unroll
+		for (int c = 0; c < CNL_; c++)
+#pragma unroll
+			for (int q = 0; q < 4; q++) { wu[c][q] = nu[c][q]; wv[c][q] = nv[c][q]; }
+		item = next;
 	}
 }
 

@@ -6,8 +6,22 @@
 namespace vfgs {
 
 constexpr int kSlots = 8;        // pattern slots per component, vfgs_hw.h:49
-constexpr int kTilePx = 128;     // luma samples per tile row (8 grain blocks)
-constexpr int kWavesPerWG = 16;  // 1024-thread workgroups, one LDS image each
+constexpr int kMaxUnits = 64;    // 8-sample units per work item row (one per lane)
+// Tuning knobs (defaults are the shipped configuration; tools/ablate.py overrides them).
+#ifndef VFGS_WAVES
+#define VFGS_WAVES 8
+#endif
+#ifndef VFGS_WG_PER_CU
+#define VFGS_WG_PER_CU 2
+#endif
+#ifndef VFGS_PREFETCH
+#define VFGS_PREFETCH 0   // 1: issue the next item's global loads before computing the current one (measured slower: VGPR spills)
+#endif
+#ifndef VFGS_ABLATE
+#define VFGS_ABLATE 0   // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py)
+#endif
+constexpr int kWavesPerWG = VFGS_WAVES;     // waves per workgroup, one LDS image each
+constexpr int kWGPerCU = VFGS_WG_PER_CU;    // resident workgroups per CU the grid is sized for
 constexpr int kBlock = 16;       // luma samples per grain block
 
 // LDS / device image of everything the kernel looks up.
@@ -19,10 +33,12 @@ constexpr int kBlock = 16;       // luma samples per grain block
 // Each bank row is padded by one 16-byte slot so consecutive rows rotate through the
 // sixteen 16-byte LDS slots of a 256-byte bank row.
 //
-// LUT entry (one dword per 8-bit intensity, per component):
-//   bits  7:0  byte selector for v_perm_b32: slot 0..7, or 0x0c (constant zero) for slot 8
+// LUT entry (one dword per 8-bit intensity; per component TWO tables of 256 entries, the
+// first with +scale, the second with -scale, so that a block's random sign can be applied by
+// choosing the table instead of multiplying every sample):
+//   bits 31:24 byte selector for v_perm_b32: slot 0..7, or 0x0c (constant zero) for slot 8
 //              (the reference's never-written 9th slot, vfgs_hw.c:49)
-//   bits 23:16 scale factor (sLUT)
+//   bits 15:0  signed scale factor (+-sLUT)
 template <int CSUBX, int CSUBY>
 struct TableLayout {
 	static constexpr int LRS = 64 * kSlots + 16;        // luma bank row stride, bytes
@@ -32,16 +48,22 @@ struct TableLayout {
 	static constexpr int LUMA_OFF = 0;
 	static constexpr int CHROMA_OFF = 64 * LRS;
 	static constexpr int LUT_OFF = CHROMA_OFF + CH * CRS;
-	static constexpr int BYTES = LUT_OFF + 3 * 256 * 4;
+	static constexpr int BYTES = LUT_OFF + 3 * 2 * 256 * 4;
 	static_assert(BYTES % 16 == 0, "image is copied in 16-byte pieces");
 };
 
-// One launch = nframes x nbr block rows x ntx tiles; one tile = 128 luma samples x one
-// block row (16 luma lines) of Y plus the co-located Cb/Cr samples, owned by ONE wavefront.
+// One launch = nframes x nbr block rows x 4 line quads x ntx tiles work items; one item =
+// `upt` units (<= 512 luma samples) x 4 luma lines of Y plus the co-located Cb/Cr samples,
+// owned by ONE wavefront.
 struct KernelArgs {
-	uint8_t* Y;               // line `y0` of frame 0 (device)
-	uint8_t* U;               // chroma row y0/csuby of frame 0
-	uint8_t* V;
+	const uint8_t* Y;         // source: line `y0` of frame 0 (device)
+	const uint8_t* U;         // source: chroma row y0/csuby of frame 0
+	const uint8_t* V;
+	uint8_t* dY;              // destination planes, same geometry (== source: in place)
+	uint8_t* dU;
+	uint8_t* dV;
+	uint32_t y_extent;        // bytes of one frame's luma stripe (rows * pitch), < 2^31: buffer range check
+	uint32_t c_extent;        // bytes of one frame's chroma stripe, per plane
 	uint64_t y_frame_pitch;   // bytes from frame f to frame f+1 (batched launches)
 	uint64_t c_frame_pitch;
 	const uint32_t* stream;   // LFSR bit stream cache (device), bit m = word[m>>5] >> (m&31)
@@ -52,7 +74,9 @@ struct KernelArgs {
 	int y0;                   // absolute luma line of the first line of the stripe
 	int nlines;               // luma lines in the stripe
 	int nblk;                 // 16-sample blocks per line = ceil(width/16), vfgs_hw.c:301
-	int ntx;                  // tiles per block row
+	int ntx;                  // tiles (work items) per line quad
+	int upt;                  // 8-sample units per tile row, even, <= 64
+	int nitems;               // nframes * nbr * 4 * ntx
 	int nbr;                  // block rows touched by the stripe
 	int stride, cstride;      // samples
 	int nframes;
