@@ -8,10 +8,11 @@ Workload (BASELINE.json `metric` / configs[4]): 7680x4320 10-bit 4:2:0, cfg fgs_
 (8 luma patterns, per-sample pattern selection), seed 12345, synthetic frames of uniformly
 random 10-bit samples generated on the GPU and resident in HBM before the timed region.
 
-A "step" processes `N x batch` frames: every frame is split into N stripes of whole 16-line
-block rows, rank r owns stripe r of every frame (no collective, no halo -- DESIGN.md
-"multi-GPU"), so per-GPU work per step is one frame's worth at every N ("weak").  At N=1 a
-step is `batch` whole frames in one launch.
+A "step" processes `N x batch` frames (default batch 8): every frame is split into N stripes of
+whole 16-line block rows, rank r owns stripe r of every frame (no collective, no halo --
+DESIGN.md "multi-GPU") and runs them in ONE launch, so per-GPU work per step is `batch`
+frames' worth at every N ("weak").  At N=1 a step is `batch` whole frames in one launch
+(`--batch 1` = one launch per frame; both are reported in DESIGN.md).
 
 `value`   = luma pixels of all frames of all ranks / wall time          [Mpixels/s]
 `roofline`= algorithmic bytes per launch (4 B per Y/Cb/Cr sample: one read + one write of
@@ -91,10 +92,10 @@ def cpu_baseline(seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1, help="frames per launch per rank-stripe set")
-    ap.add_argument("--pool", type=int, default=24, help="distinct frame buffers cycled through (>= 256 MiB of data)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="frames per launch per rank (a step = gpus*batch frames)")
+    ap.add_argument("--pool", type=int, default=4, help="distinct step-sized buffer sets cycled through (total >> 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -167,8 +168,10 @@ def main():
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"            # PMC-derived bytes per launch, if collected
-        if tf.exists() and world == 1 and args.batch == 1:
-            traffic = json.loads(tf.read_text()).get("bytes_per_launch")
+        if tf.exists() and world == 1:
+            rec = json.loads(tf.read_text())                     # measured with rocprofv3 --pmc on this command
+            if rec.get("batch") == args.batch:
+                traffic = rec.get("bytes_per_launch")
         out = {
             "metric": "Mpixels/s (Y+UV) + achieved HBM GB/s vs roofline, 4320p 10-bit 4:2:0",
             "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

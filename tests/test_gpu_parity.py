@@ -210,3 +210,40 @@ def test_zero_scale_is_clip_only_at_full_size(hip):
         torch.cuda.synchronize()
         for a, b in zip((Y, U, V), ref):
             assert torch.equal(a, b)
+
+
+def test_unchanged_reference_cli_linked_against_hip_library(hip, tmp_path):
+    """DROP-IN: the reference's own vfgs_main.c + vfgs_fw.c + yuv.c, compiled unmodified and
+    linked against libvfgs_hip.so (oracle/_ref/vfgs_hip_cli), must write the same file as the
+    all-reference binary (oracle/_ref/vfgs_ref).  Both prebuilt in the build container; the cfg
+    below is written here (the reference's cfg corpus does not travel)."""
+    import subprocess
+    cli, ref = T.REF_DIR / "vfgs_hip_cli", T.REF_DIR / "vfgs_ref"
+    if not (cli.exists() and ref.exists()):
+        pytest.skip("oracle/_ref binaries were not prebuilt")
+    cfg = tmp_path / "two_patterns.cfg"
+    cfg.write_text("\n".join([
+        "SEIFGCModelID : 0", "SEIFGCLog2ScaleFactor : 4",
+        "SEIFGCCompModelPresentComp0 : 1", "SEIFGCCompModelPresentComp1 : 1", "SEIFGCCompModelPresentComp2 : 1",
+        "SEIFGCNumIntensityIntervalMinus1Comp0 : 2", "SEIFGCNumIntensityIntervalMinus1Comp1 : 0",
+        "SEIFGCNumIntensityIntervalMinus1Comp2 : 1",
+        "SEIFGCNumModelValuesMinus1Comp0 : 2", "SEIFGCNumModelValuesMinus1Comp1 : 2", "SEIFGCNumModelValuesMinus1Comp2 : 2",
+        "SEIFGCIntensityIntervalLowerBoundComp0 : 0 70 150", "SEIFGCIntensityIntervalUpperBoundComp0 : 69 149 255",
+        "SEIFGCIntensityIntervalLowerBoundComp1 : 0", "SEIFGCIntensityIntervalUpperBoundComp1 : 255",
+        "SEIFGCIntensityIntervalLowerBoundComp2 : 0 128", "SEIFGCIntensityIntervalUpperBoundComp2 : 127 255",
+        "SEIFGCCompModelValuesComp0 : 90 6 9 120 10 10 60 13 4",
+        "SEIFGCCompModelValuesComp1 : 70 5 5", "SEIFGCCompModelValuesComp2 : 40 4 6 80 7 3", ""]))
+    w, h, n = 208, 160, 3
+    for depth in (10, 8):
+        frames, _ = T.lcg_frames(w, h, depth, 2, 2, n)
+        inp = tmp_path / f"in{depth}.yuv"
+        inp.write_bytes(b"".join(f.picture_bytes() for f in frames))
+        outs = []
+        for exe in (ref, cli):
+            out = tmp_path / f"{exe.name}_{depth}.yuv"
+            subprocess.run([str(exe), "-w", str(w), "-h", str(h), "-b", str(depth), "-n", str(n), "-r", "777",
+                            "-c", str(cfg), str(inp), str(out)], check=True, stdout=subprocess.DEVNULL, timeout=600)
+            outs.append(out.read_bytes())
+        assert len(outs[0]) == len(inp.read_bytes())
+        assert outs[0] != inp.read_bytes()          # grain was really added
+        assert outs[0] == outs[1]

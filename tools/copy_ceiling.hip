@@ -85,6 +85,41 @@ __global__ void k_tiles(const uint8_t* src, uint8_t* dst, int pitch, int ntx, in
 	}
 }
 
+// chroma-shaped rows: 8-byte (not 16-byte) aligned 16-byte pieces, as one b128 or as two b64 accesses
+template <int ROWS, bool SPLIT>
+__global__ void k_tiles8(const uint8_t* src, uint8_t* dst, int pitch, int ntx, int upt, int nrowgroups)
+{
+	typedef uint32_t v4a8 __attribute__((ext_vector_type(4), aligned(8)));
+	typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+	const int wave = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int nwaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+	const int lane = threadIdx.x & 63;
+	for (int item = wave; item < ntx * nrowgroups; item += nwaves)
+	{
+		const int tx = item % ntx, rg = item / ntx;
+		const long off = (long)(tx * upt + lane) * 16 - 8;
+		const bool ok = lane < upt && off >= 0 && off + 16 <= pitch;
+		u32x4 v[ROWS];
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+			if (ok)
+			{
+				const uint8_t* p = src + (size_t)(rg * ROWS + r) * pitch + off;
+				if (SPLIT) { v2 a = *(const v2*)p, b2 = *(const v2*)(p + 8); v[r] = u32x4{a.x, a.y, b2.x, b2.y}; }
+				else v[r] = *(const v4a8*)p;
+			}
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+			if (ok)
+			{
+				uint8_t* p = dst + (size_t)(rg * ROWS + r) * pitch + off;
+				u32x4 o = v[r] + 1u;
+				if (SPLIT) { *(v2*)p = v2{o.x, o.y}; *(v2*)(p + 8) = v2{o.z, o.w}; }
+				else *(v4a8*)p = o;
+			}
+	}
+}
+
 int main()
 {
 	const size_t bytes = 199065600ull / 2;       // one 4320p 10-bit 4:2:0 frame
@@ -127,6 +162,8 @@ int main()
 			run("tiles 64u aligned in-place", [&](int i) { k_tiles<4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 15, 64, rows / 4, 0); });
 			run("tiles 64u aligned out-of-place", [&](int i) { k_tiles<4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)b, pitch, 15, 64, rows / 4, 0); });
 			run("tiles 64u shift16 out-of-place", [&](int i) { k_tiles<4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)b, pitch, 16, 64, rows / 4, 16); });
+			run("tiles 62u shift8 b128 in-place", [&](int i) { k_tiles8<4, false><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 16, 62, rows / 4); });
+			run("tiles 62u shift8 2xb64 in-place", [&](int i) { k_tiles8<4, true><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 16, 62, rows / 4); });
 			run("tiles 60u aligned-ish out-of-place", [&](int i) { k_tiles<4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)b, pitch, 16, 60, rows / 4, 0); });
 		}
 		run("rmw rows x4 buffer ops", [&](int i) { k_rmw_rows_buf<4, false><<<blocks, threads>>>(a[i], n); });

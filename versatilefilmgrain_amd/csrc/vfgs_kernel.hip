@@ -48,6 +48,21 @@ __device__ __forceinline__ uint32_t stream_window(const uint32_t* __restrict__ s
 	return __builtin_amdgcn_alignbit(hi, lo, bit & 31);
 }
 
+// The same in two steps: the two dwords are fetched together with the item's sample loads
+// (so that no later wait on them drains younger loads or older stores: vmcnt retires in
+// order), the window is cut out when the block parameters are needed.
+__device__ __forceinline__ void stream_fetch(const uint32_t* __restrict__ s, uint32_t bit, uint32_t (&raw)[2])
+{
+	const uint32_t* p = s + (bit >> 5);
+	raw[0] = p[0];
+	raw[1] = p[1];
+}
+
+__device__ __forceinline__ uint32_t stream_cut(const uint32_t (&raw)[2], uint32_t bit)
+{
+	return __builtin_amdgcn_alignbit(raw[1], raw[0], bit & 31);
+}
+
 struct BlockParam {
 	uint32_t addr;  // LDS byte offset of bank[.][oy][ox][slot 0]
 	int sign;       // +1 / -1
@@ -302,17 +317,22 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 // Subsampled chroma (8-sample blocks): one lane owns the 8 chroma samples around block edge
 // m, i.e. the second half of block m-1 and the first half of block m; 32 lanes per row.
 
-// One work item (see "Geometry" above).  SPLIT = the item touches the left or right picture
-// edge, where a subsampled-chroma lane can own only one valid half: those items move chroma in
-// two 8-byte halves per lane, all others in one 16-byte access.
-//
-// PHASE 0 issues the item's global loads into (wy, wu, wv) and returns; PHASE 1 takes those
-// registers, computes and stores.  The kernel runs PHASE 0 of the NEXT item before PHASE 1 of
-// the current one, so every wave has its next loads in flight while it computes.
+// One work item (see "Geometry" above), in four phases so that the kernel can interleave two
+// items: LOAD_Y / LOAD_C issue the global loads of the luma / chroma rows into registers,
+// COMP_Y / COMP_C compute and store them.  The kernel's order per item is
+//     LOAD_C(i), COMP_Y(i), LOAD_Y(i+1), COMP_C(i)
+// so a wave always has loads in flight while it computes, with no more registers than one
+// item's worth of data (the luma registers are refilled as soon as they have been stored).
+// SPLITC = the item touches the left or right picture edge, where a subsampled-chroma lane can
+// own only one valid half: those items move chroma in two 8-byte halves per lane, all others
+// in one 16-byte access.
+enum { LOAD_Y = 0, LOAD_C = 1, COMP_Y = 2, COMP_C = 3 };
+
 template <int DEPTH, int CSUBX, int CSUBY, bool SPLITC, int PHASE>
 __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds, const int item, const int lane,
                                         uint32_t (&wy)[4][4], uint32_t (&wu)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4],
-                                        uint32_t (&wv)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4])
+                                        uint32_t (&wv)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4],
+                                        uint32_t (&sy)[2][2], uint32_t (&sc)[4][2])
 {
 	using L = TableLayout<CSUBX, CSUBY>;
 	constexpr int SZ = DEPTH > 8 ? 2 : 1;
@@ -321,14 +341,13 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 	constexpr int CRPL = (CBW == 16) ? 1 : 2;     // chroma rows per wave access
 	constexpr int CNL = CROWS / CRPL;             // chroma accesses per plane per item
 	constexpr uint32_t LUTY = L::LUT_OFF, LUTU = L::LUT_OFF + 2048, LUTV = L::LUT_OFF + 4096;   // [+scale | -scale] each
-
 	constexpr bool SPLIT = SPLITC && (CBW != 16);
+	constexpr bool LUMA = (PHASE == LOAD_Y || PHASE == COMP_Y);
+	constexpr bool COMP = (PHASE == COMP_Y || PHASE == COMP_C);
+
 	const int nunits = 2 * a.nblk;
 	const int last = a.nblk - 1;
 	const int half = 1 << (a.scale_shift - 1);
-	const uint32_t ylo2 = (uint32_t)a.ylo * 0x10001u, yhi2 = (uint32_t)a.yhi * 0x10001u;
-	const uint32_t clo2 = (uint32_t)a.clo * 0x10001u, chi2 = (uint32_t)a.chi * 0x10001u;
-
 
 	// item -> (frame f, block row k of the stripe, line quad p, tile tx); tx fastest
 	int t = item;
@@ -340,42 +359,90 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 	const bool has_up = (R > 0) && (p == 0);      // lines j = 0, 1 of a block row below the first (vfgs_hw.c:175,180)
 
 	// whole item outside the stripe (only for stripes that are not multiples of 16 lines)?
-	if (PHASE == 1 && (16 * R + 4 * p + 3 < a.y0 || 16 * R + 4 * p >= a.y0 + a.nlines))
+	if (COMP && (16 * R + 4 * p + 3 < a.y0 || 16 * R + 4 * p >= a.y0 + a.nlines))
 		return;
 
-	// one descriptor per plane of this frame's stripe; num_records = its exact extent, so the
-	// hardware bounds-checks every access of the item
 	const uint32_t yrow = (uint32_t)(a.stride * SZ), crow = (uint32_t)(a.cstride * SZ);
-	const __amdgpu_buffer_rsrc_t sY = make_rsrc(a.Y + (uint64_t)f * a.y_frame_pitch, a.y_extent);
-	const __amdgpu_buffer_rsrc_t sU = make_rsrc(a.U + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-	const __amdgpu_buffer_rsrc_t sV = make_rsrc(a.V + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-	const __amdgpu_buffer_rsrc_t dY = make_rsrc(a.dY + (uint64_t)f * a.y_frame_pitch, a.y_extent);
-	const __amdgpu_buffer_rsrc_t dU = make_rsrc(a.dU + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-	const __amdgpu_buffer_rsrc_t dV = make_rsrc(a.dV + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-
 	const int j0 = tx * a.upt - 1;                // first unit of this item
-
-	// ---- issue every global load of the item first ------------------------------------
-	// luma: one row per access
-	const int ju = j0 + lane;
+	const int ju = j0 + lane;                     // this lane's unit (luma, and chroma when CBW == 16)
 	const bool l_ok = (lane < a.upt) && (ju >= 0) && (ju < nunits);
 	const bool l_first = !(ju & 1);               // first half of its block
-	uint32_t voy[4];
+	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(k * a.nblk);
+	const uint32_t up_bit = (k > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
+	const int yblk = min(max(ju >> 1, 0), last);
+
+	if (LUMA)
+	{
+		// one descriptor per plane of this frame's stripe; num_records = its exact extent, so the
+		// hardware bounds-checks every access of the item
+		const __amdgpu_buffer_rsrc_t sY = make_rsrc(a.Y + (uint64_t)f * a.y_frame_pitch, a.y_extent);
+		const __amdgpu_buffer_rsrc_t dY = make_rsrc(a.dY + (uint64_t)f * a.y_frame_pitch, a.y_extent);
+		uint32_t voy[4];
 #pragma unroll
-	for (int r = 0; r < 4; r++)
-	{
-		const int yabs = 16 * R + 4 * p + r;
-		const bool rok = (yabs >= a.y0) && (yabs < a.y0 + a.nlines);          // wave-uniform
-		// a line outside the stripe is computed but neither read nor written (all lanes out of range)
-		voy[r] = (rok && l_ok) ? (uint32_t)(yabs - a.y0) * yrow + (uint32_t)(8 * ju * SZ) : kOOB;
-		if (PHASE == 0) load_unit<DEPTH, false>(sY, voy[r], 0, 0, wy[r]);
+		for (int r = 0; r < 4; r++)
+		{
+			const int yabs = 16 * R + 4 * p + r;
+			const bool rok = (yabs >= a.y0) && (yabs < a.y0 + a.nlines);          // wave-uniform
+			// a line outside the stripe is computed but neither read nor written (all lanes out of range)
+			voy[r] = (rok && l_ok) ? (uint32_t)(yabs - a.y0) * yrow + (uint32_t)(8 * ju * SZ) : kOOB;
+			if (PHASE == LOAD_Y) load_unit<DEPTH, false>(sY, voy[r], 0, 0, wy[r]);
+		}
+		if (PHASE == LOAD_Y)
+		{
+			stream_fetch(a.stream, cur_bit + yblk, sy[0]);
+			if (has_up) stream_fetch(a.stream, up_bit + yblk, sy[1]);
+			return;
+		}
+
+		const uint32_t ylo2 = (uint32_t)a.ylo * 0x10001u, yhi2 = (uint32_t)a.yhi * 0x10001u;
+		const uint32_t vy = stream_cut(sy[0], cur_bit + yblk);
+		const BlockParam ycur = block_param<0, 1, 1, L::LRS>(vy, L::LUMA_OFF);
+		// edge between this lane pair: left unit must exist (>= 0), right unit must exist (< nunits)
+		const int jl = l_first ? ju - 1 : ju;
+		const bool edge_on = (lane < a.upt) && (jl >= 0) && (jl + 1 < nunits);
+		const uint32_t hoff = l_first ? 0u : 8u * kSlots;
+		const uint32_t base = ycur.addr + hoff;
+		if (has_up)   // wave-uniform: lines 0 and 1 blend with the block row above
+		{
+			const BlockParam yup = block_param<0, 1, 1, L::LRS>(stream_cut(sy[1], up_bit + yblk), L::LUMA_OFF);
+			const uint32_t ubase = yup.addr + 16u * L::LRS + hoff;
+#pragma unroll
+			for (int r = 0; r < 2; r++)
+			{
+				const uint32_t rowoff = (uint32_t)(4 * p + r) * L::LRS;   // scalar
+				const int wc = (r == 0) ? 12 : 24, wu_ = (r == 0) ? 24 : 12;   // vfgs_hw.c:177-183, suby == 1
+				grain_unit<DEPTH, true, true>(lds, wy[r], LUTY, LUTY, base + rowoff, base + rowoff + 4 * kSlots,
+				                              ycur.sign * wc, ycur.sign * wc,
+				                              ubase + rowoff, ubase + rowoff + 4 * kSlots, yup.sign * wu_, yup.sign * wu_,
+				                              edge_on, l_first, 1, 2, 2, a.scale_shift, half, ylo2, yhi2);
+				store_unit<DEPTH, false>(dY, voy[r], 0, 0, wy[r]);
+			}
+		}
+		const int rel = __mul24(ycur.sign, swap_lane_pairs(ycur.sign));    // relative sign of the two blocks at the edge
+		const uint32_t luts = LUTY + (ycur.sign < 0 ? 1024u : 0u);
+		const int cs = ycur.sign < 0 ? 1 : 2;
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+		{
+			if (r < 2 && has_up)
+				continue;
+			const uint32_t rowoff = (uint32_t)(4 * p + r) * L::LRS;   // scalar
+			grain_unit<DEPTH, false, true>(lds, wy[r], luts, luts, base + rowoff, base + rowoff + 4 * kSlots,
+			                               0, 0, 0, 0, 0, 0,
+			                               edge_on, l_first, rel, cs, cs, a.scale_shift, half, ylo2, yhi2);
+			store_unit<DEPTH, false>(dY, voy[r], 0, 0, wy[r]);
+		}
 	}
-	// chroma
-	uint32_t cv0[CNL], cv1[CNL];
-	int crl[CNL];                                  // chroma row inside the block row, per access
-	int cm;                                        // CBW == 8: block edge index m; CBW == 16: unit index
-	bool c_first = false;
+	else
 	{
+		const __amdgpu_buffer_rsrc_t sU = make_rsrc(a.U + (uint64_t)f * a.c_frame_pitch, a.c_extent);
+		const __amdgpu_buffer_rsrc_t sV = make_rsrc(a.V + (uint64_t)f * a.c_frame_pitch, a.c_extent);
+		const __amdgpu_buffer_rsrc_t dU = make_rsrc(a.dU + (uint64_t)f * a.c_frame_pitch, a.c_extent);
+		const __amdgpu_buffer_rsrc_t dV = make_rsrc(a.dV + (uint64_t)f * a.c_frame_pitch, a.c_extent);
+		uint32_t cv0[CNL], cv1[CNL];
+		int crl[CNL];                                  // chroma row inside the block row, per access
+		int cm;                                        // CBW == 8: block edge index m; CBW == 16: unit index
+		bool c_first = false;
 		bool h0, h1;
 		int xc0;
 		if (CBW == 16)
@@ -404,104 +471,55 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 			const uint32_t rowb = (uint32_t)(prow - a.y0 / CSUBY) * crow;
 			cv0[c] = (rok && h0) ? rowb + (uint32_t)(xc0 * SZ) : kOOB;
 			cv1[c] = (rok && h1) ? rowb + (uint32_t)((xc0 + 4) * SZ) : kOOB;
-			if (PHASE == 0)
+			if (PHASE == LOAD_C)
 			{
 				load_unit<DEPTH, SPLIT>(sU, cv0[c], cv1[c], 0, wu[c]);
 				load_unit<DEPTH, SPLIT>(sV, cv0[c], cv1[c], 0, wv[c]);
 			}
 		}
-	}
-	if (PHASE == 0)
-		return;
+		int cbl, cbr;                                  // blocks left / right of the lane's edge
+		if (CBW == 16) { cbl = cbr = yblk; }
+		else { cbl = min(max(cm - 1, 0), last); cbr = min(cm, last); }
+		if (PHASE == LOAD_C)
+		{
+			stream_fetch(a.stream, cur_bit + cbl, sc[0]);
+			if (CBW != 16) stream_fetch(a.stream, cur_bit + cbr, sc[1]);
+			if (has_up)
+			{
+				stream_fetch(a.stream, up_bit + cbl, sc[2]);
+				if (CBW != 16) stream_fetch(a.stream, up_bit + cbr, sc[3]);
+			}
+			return;
+		}
 
-	// ---- LFSR windows -> pattern addresses and signs ------------------------------------
-	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(k * a.nblk);
-	const uint32_t up_bit = (k > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
-
-	const int yblk = min(max(ju >> 1, 0), last);
-	const uint32_t vy = stream_window(a.stream, cur_bit + yblk);
-	const BlockParam ycur = block_param<0, 1, 1, L::LRS>(vy, L::LUMA_OFF);
-	int cbl, cbr;                                  // chroma: blocks left / right of the lane's edge
-	if (CBW == 16) { cbl = cbr = yblk; }
-	else { cbl = min(max(cm - 1, 0), last); cbr = min(cm, last); }
-	const uint32_t vcl = (CBW == 16) ? vy : stream_window(a.stream, cur_bit + cbl);
-	const uint32_t vcr = (CBW == 16) ? vy : stream_window(a.stream, cur_bit + cbr);
-	const BlockParam ucur0 = block_param<1, CSUBX, CSUBY, L::CRS>(vcl, L::CHROMA_OFF);
-	const BlockParam vcur0 = block_param<2, CSUBX, CSUBY, L::CRS>(vcl, L::CHROMA_OFF);
-	BlockParam ucur1 = ucur0, vcur1 = vcur0;
-	if (CBW != 16)
-	{
-		ucur1 = block_param<1, CSUBX, CSUBY, L::CRS>(vcr, L::CHROMA_OFF);
-		vcur1 = block_param<2, CSUBX, CSUBY, L::CRS>(vcr, L::CHROMA_OFF);
-	}
-	BlockParam yup = ycur, uup0 = ucur0, uup1 = ucur1, vup0 = vcur0, vup1 = vcur1;
-	if (has_up)   // wave-uniform
-	{
-		const uint32_t wyu = stream_window(a.stream, up_bit + yblk);
-		yup = block_param<0, 1, 1, L::LRS>(wyu, L::LUMA_OFF);
-		const uint32_t wl = (CBW == 16) ? wyu : stream_window(a.stream, up_bit + cbl);
-		uup0 = uup1 = block_param<1, CSUBX, CSUBY, L::CRS>(wl, L::CHROMA_OFF);
-		vup0 = vup1 = block_param<2, CSUBX, CSUBY, L::CRS>(wl, L::CHROMA_OFF);
+		const uint32_t clo2 = (uint32_t)a.clo * 0x10001u, chi2 = (uint32_t)a.chi * 0x10001u;
+		const uint32_t vcl = stream_cut(sc[0], cur_bit + cbl);
+		const uint32_t vcr = (CBW == 16) ? vcl : stream_cut(sc[1], cur_bit + cbr);
+		const BlockParam ucur0 = block_param<1, CSUBX, CSUBY, L::CRS>(vcl, L::CHROMA_OFF);
+		const BlockParam vcur0 = block_param<2, CSUBX, CSUBY, L::CRS>(vcl, L::CHROMA_OFF);
+		BlockParam ucur1 = ucur0, vcur1 = vcur0;
 		if (CBW != 16)
 		{
-			const uint32_t wr = stream_window(a.stream, up_bit + cbr);
-			uup1 = block_param<1, CSUBX, CSUBY, L::CRS>(wr, L::CHROMA_OFF);
-			vup1 = block_param<2, CSUBX, CSUBY, L::CRS>(wr, L::CHROMA_OFF);
+			ucur1 = block_param<1, CSUBX, CSUBY, L::CRS>(vcr, L::CHROMA_OFF);
+			vcur1 = block_param<2, CSUBX, CSUBY, L::CRS>(vcr, L::CHROMA_OFF);
 		}
-	}
-
-	// ---- luma rows -----------------------------------------------------------------------
-	{
-		// edge between this lane pair: left unit must exist (>= 0), right unit must exist (< nunits)
-		const int jl = l_first ? ju - 1 : ju;
-		const bool edge_on = (lane < a.upt) && (jl >= 0) && (jl + 1 < nunits);
-		const uint32_t hoff = l_first ? 0u : 8u * kSlots;
-		const uint32_t base = ycur.addr + hoff;
-		const uint32_t ubase = yup.addr + 16u * L::LRS + hoff;
-		const int rel = __mul24(ycur.sign, swap_lane_pairs(ycur.sign));    // relative sign of the two blocks at the edge
-		const uint32_t luts = LUTY + (ycur.sign < 0 ? 1024u : 0u);
-		const int cs = ycur.sign < 0 ? 1 : 2;
-#pragma unroll
-		for (int r = 0; r < 4; r++)
-		{
-			const uint32_t rowoff = (uint32_t)(4 * p + r) * L::LRS;   // scalar
-			if (r < 2 && has_up)
-			{
-				const int wc = (r == 0) ? 12 : 24, wu_ = (r == 0) ? 24 : 12;   // vfgs_hw.c:177-183, suby == 1
-				grain_unit<DEPTH, true, true>(lds, wy[r], LUTY, LUTY, base + rowoff, base + rowoff + 4 * kSlots,
-				                              ycur.sign * wc, ycur.sign * wc,
-				                              ubase + rowoff, ubase + rowoff + 4 * kSlots, yup.sign * wu_, yup.sign * wu_,
-				                              edge_on, l_first, 1, 2, 2, a.scale_shift, half, ylo2, yhi2);
-			}
-			else
-			{
-				grain_unit<DEPTH, false, true>(lds, wy[r], luts, luts, base + rowoff, base + rowoff + 4 * kSlots,
-				                               0, 0, 0, 0, 0, 0,
-				                               edge_on, l_first, rel, cs, cs, a.scale_shift, half, ylo2, yhi2);
-			}
-			store_unit<DEPTH, false>(dY, voy[r], 0, 0, wy[r]);
-		}
-	}
-
-	// ---- chroma rows ---------------------------------------------------------------------
-	{
 		bool edge_on;
-		uint32_t h0, h1;
+		uint32_t g0, g1;
 		int relu, relv;
 		if (CBW == 16)
 		{
 			const int jl = c_first ? ju - 1 : ju;
 			edge_on = (lane < a.upt) && (jl >= 0) && (jl + 1 < nunits);
-			h0 = c_first ? 0u : 8u * kSlots;
-			h1 = h0 + 4 * kSlots;
+			g0 = c_first ? 0u : 8u * kSlots;
+			g1 = g0 + 4 * kSlots;
 			relu = __mul24(ucur0.sign, swap_lane_pairs(ucur0.sign));
 			relv = __mul24(vcur0.sign, swap_lane_pairs(vcur0.sign));
 		}
 		else
 		{
 			edge_on = ((lane & 31) < a.upt / 2) && (cm - 1 >= 0) && (cm <= last);
-			h0 = 4 * kSlots;   // samples 4..7 of the left block
-			h1 = 0;            // samples 0..3 of the right block
+			g0 = 4 * kSlots;   // samples 4..7 of the left block
+			g1 = 0;            // samples 0..3 of the right block
 			relu = __mul24(ucur0.sign, ucur1.sign);
 			relv = __mul24(vcur0.sign, vcur1.sign);
 		}
@@ -513,19 +531,25 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 		for (int c = 0; c < CNL; c++)
 		{
 			const uint32_t rowoff = __umul24((uint32_t)crl[c], (uint32_t)L::CRS);
-			const uint32_t ua0 = ucur0.addr + rowoff + h0, ua1 = ucur1.addr + rowoff + h1;
-			const uint32_t va0 = vcur0.addr + rowoff + h0, va1 = vcur1.addr + rowoff + h1;
+			const uint32_t ua0 = ucur0.addr + rowoff + g0, ua1 = ucur1.addr + rowoff + g1;
+			const uint32_t va0 = vcur0.addr + rowoff + g0, va1 = vcur1.addr + rowoff + g1;
 			// only accesses whose first row is line j = row * CSUBY <= 1 of the block row can hold overlap lines
 			if (has_up && (CRPL * c * CSUBY <= 1))
 			{
+				const uint32_t wl = stream_cut(sc[2], up_bit + cbl);
+				const uint32_t wr = (CBW == 16) ? wl : stream_cut(sc[3], up_bit + cbr);
+				const BlockParam uup0 = block_param<1, CSUBX, CSUBY, L::CRS>(wl, L::CHROMA_OFF);
+				const BlockParam vup0 = block_param<2, CSUBX, CSUBY, L::CRS>(wl, L::CHROMA_OFF);
+				const BlockParam uup1 = (CBW == 16) ? uup0 : block_param<1, CSUBX, CSUBY, L::CRS>(wr, L::CHROMA_OFF);
+				const BlockParam vup1 = (CBW == 16) ? vup0 : block_param<2, CSUBX, CSUBY, L::CRS>(wr, L::CHROMA_OFF);
 				const int jj = crl[c] * CSUBY;
 				int wc = 32, wu_ = 0;
 				if (jj == 0) { wc = CSUBY > 1 ? 20 : 12; wu_ = CSUBY > 1 ? 20 : 24; }
 				else if (jj == 1) { wc = 24; wu_ = 12; }
 				const uint32_t uoff = (16 / CSUBY) * L::CRS + rowoff;
 				// lanes without overlap must not read past the bank: point their (unused) read at the current row
-				const uint32_t uu0 = wu_ ? uup0.addr + uoff + h0 : ua0, uu1 = wu_ ? uup1.addr + uoff + h1 : ua1;
-				const uint32_t vu0 = wu_ ? vup0.addr + uoff + h0 : va0, vu1 = wu_ ? vup1.addr + uoff + h1 : va1;
+				const uint32_t uu0 = wu_ ? uup0.addr + uoff + g0 : ua0, uu1 = wu_ ? uup1.addr + uoff + g1 : ua1;
+				const uint32_t vu0 = wu_ ? vup0.addr + uoff + g0 : va0, vu1 = wu_ ? vup1.addr + uoff + g1 : va1;
 				grain_unit<DEPTH, true, CBW == 16>(lds, wu[c], LUTU, LUTU, ua0, ua1, __mul24(ucur0.sign, wc), __mul24(ucur1.sign, wc),
 				                                   uu0, uu1, __mul24(uup0.sign, wu_), __mul24(uup1.sign, wu_),
 				                                   edge_on, c_first, 1, 2, 2, a.scale_shift, half, clo2, chi2);
@@ -550,12 +574,7 @@ template <int DEPTH, int CSUBX, int CSUBY>
 __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4) void grain_kernel(const KernelArgs a)
 {
 	using L = TableLayout<CSUBX, CSUBY>;
-	constexpr int SZ = DEPTH > 8 ? 2 : 1;
-	constexpr int CBW = 16 / CSUBX;               // chroma block width in samples
-	constexpr int CROWS = 4 / CSUBY;              // chroma rows per item (4 luma lines)
-	constexpr int CRPL = (CBW == 16) ? 1 : 2;     // chroma rows per wave access
-	constexpr int CNL = CROWS / CRPL;             // chroma accesses per plane per item
-	constexpr uint32_t LUTY = L::LUT_OFF, LUTU = L::LUT_OFF + 2048, LUTV = L::LUT_OFF + 4096;   // [+scale | -scale] each
+	constexpr int CNL_ = (4 / CSUBY) / ((CSUBX == 1) ? 1 : 2);
 
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L::BYTES];
 
@@ -570,50 +589,60 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4)
 	// wave-uniform by construction; telling the compiler keeps item decoding, row offsets and
 	// buffer descriptors in SGPRs (otherwise every buffer instruction gets a waterfall loop)
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
 	// persistent: the workgroups of one launch share the items round-robin, kWavesPerWG
 	// consecutive items (neighbouring tiles of one line quad) per workgroup and step.
 	// A lane of the first tile of a row has no block to its left; a tile whose last block edge
 	// index exceeds the last block has lanes with no block to their right: those tiles take the
 	// SPLIT form of do_item (wave-uniform test).
-	constexpr int CNL_ = (4 / CSUBY) / ((CSUBX == 1) ? 1 : 2);
+#if VFGS_CHUNKED
+	// each workgroup walks one contiguous run of items (tiles along a row, then the next rows)
+	const int step = kWavesPerWG;
+	const int per_wg = ((a.nitems + (int)gridDim.x - 1) / (int)gridDim.x + kWavesPerWG - 1) / kWavesPerWG * kWavesPerWG;
+	int item = blockIdx.x * per_wg + wave;
+	const int item_end = min(a.nitems, (int)(blockIdx.x + 1) * per_wg);
+#define VFGS_NITEMS item_end
+#else
 	const int step = gridDim.x * kWavesPerWG;
 	int item = blockIdx.x * kWavesPerWG + wave;
-	if (item >= a.nitems)
+#define VFGS_NITEMS a.nitems
+#endif
+	if (item >= VFGS_NITEMS)
 		return;
 	auto is_split = [&](int it) { const int tx = it % a.ntx; return tx == 0 || (tx + 1) * (a.upt / 2) > a.nblk; };
 
 	uint32_t wy[4][4], wu[CNL_][4], wv[CNL_][4];
-	if (is_split(item)) do_item<DEPTH, CSUBX, CSUBY, true, 0>(a, lds, item, lane, wy, wu, wv);
-	else                do_item<DEPTH, CSUBX, CSUBY, false, 0>(a, lds, item, lane, wy, wu, wv);
+	uint32_t sy[2][2], sc[4][2];      // raw LFSR stream dwords of the item's blocks (luma / chroma; current, upper row)
+#define VFGS_PHASE(PH, IT)                                                                                      \
+	do {                                                                                                        \
+		if (is_split(IT)) do_item<DEPTH, CSUBX, CSUBY, true, PH>(a, lds, IT, lane, wy, wu, wv, sy, sc);        \
+		else              do_item<DEPTH, CSUBX, CSUBY, false, PH>(a, lds, IT, lane, wy, wu, wv, sy, sc);       \
+	} while (0)
+
+#if VFGS_PIPE
+	VFGS_PHASE(LOAD_Y, item);
 	for (;;)
 	{
 		const int next = item + step;
-		uint32_t ny[4][4], nu[CNL_][4], nv[CNL_][4];
-#if VFGS_PREFETCH
-		if (next < a.nitems)
-		{
-			if (is_split(next)) do_item<DEPTH, CSUBX, CSUBY, true, 0>(a, lds, next, lane, ny, nu, nv);
-			else                do_item<DEPTH, CSUBX, CSUBY, false, 0>(a, lds, next, lane, ny, nu, nv);
-		}
-#endif
-		if (is_split(item)) do_item<DEPTH, CSUBX, CSUBY, true, 1>(a, lds, item, lane, wy, wu, wv);
-		else                do_item<DEPTH, CSUBX, CSUBY, false, 1>(a, lds, item, lane, wy, wu, wv);
-		if (next >= a.nitems)
+		VFGS_PHASE(LOAD_C, item);
+		VFGS_PHASE(COMP_Y, item);
+		if (next < VFGS_NITEMS)
+			VFGS_PHASE(LOAD_Y, next);      // the luma registers are free again: refill them now
+		VFGS_PHASE(COMP_C, item);
+		if (next >= VFGS_NITEMS)
 			break;
-#if !VFGS_PREFETCH
-		if (is_split(next)) do_item<DEPTH, CSUBX, CSUBY, true, 0>(a, lds, next, lane, ny, nu, nv);
-		else                do_item<DEPTH, CSUBX, CSUBY, false, 0>(a, lds, next, lane, ny, nu, nv);
-#endif
-#pragma unroll
-		for (int r = 0; r < 4; r++)
-#pragma unroll
-			for (int q = 0; q < 4; q++) wy[r][q] = ny[r][q];
-#pragma unroll
-		for (int c = 0; c < CNL_; c++)
-#pragma unroll
-			for (int q = 0; q < 4; q++) { wu[c][q] = nu[c][q]; wv[c][q] = nv[c][q]; }
 		item = next;
 	}
+#else
+	for (; item < VFGS_NITEMS; item += step)
+	{
+		VFGS_PHASE(LOAD_Y, item);
+		VFGS_PHASE(LOAD_C, item);
+		VFGS_PHASE(COMP_Y, item);
+		VFGS_PHASE(COMP_C, item);
+	}
+#endif
+#undef VFGS_PHASE
 }
 
 // ---------------------------------------------------------------------------------------

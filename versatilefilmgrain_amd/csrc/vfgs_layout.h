@@ -14,8 +14,11 @@ constexpr int kMaxUnits = 64;    // 8-sample units per work item row (one per la
 #ifndef VFGS_WG_PER_CU
 #define VFGS_WG_PER_CU 2
 #endif
-#ifndef VFGS_PREFETCH
-#define VFGS_PREFETCH 0   // 1: issue the next item's global loads before computing the current one (measured slower: VGPR spills)
+#ifndef VFGS_CHUNKED
+#define VFGS_CHUNKED 0    // 1: every workgroup gets one contiguous run of items instead of round-robin
+#endif
+#ifndef VFGS_PIPE
+#define VFGS_PIPE 1       // 1: LOAD_C(i), COMP_Y(i), LOAD_Y(i+1), COMP_C(i); 0: load all of item i, then compute it
 #endif
 #ifndef VFGS_ABLATE
 #define VFGS_ABLATE 0   // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py)
