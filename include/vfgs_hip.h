@@ -120,6 +120,17 @@ int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, 
                                 unsigned stride, unsigned cstride, unsigned nframes,
                                 uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes, void* stream);
 
+/* The same with the output narrowed to 8 bit in the store: dst sample = (uint8)((v + 2) >> 2),
+ * i.e. the reference CLI's `--outdepth 8` step yuv_to_8bit (yuv.c:216-258, called at
+ * vfgs_main.c:787-788) fused into the kernel.  Needs vfgs_set_depth(10).  Source planes hold
+ * uint16 samples (strides in samples), destination planes uint8 samples with their own strides
+ * and frame pitches (multiples of 16).  Halves the write traffic of the path. */
+int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV,
+                                 unsigned width, unsigned frame_height, unsigned part_y, unsigned part_height,
+                                 unsigned stride, unsigned cstride, unsigned dst_stride, unsigned dst_cstride,
+                                 unsigned nframes, uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes,
+                                 uint64_t dst_y_frame_pitch_bytes, uint64_t dst_c_frame_pitch_bytes, void* stream);
+
 /* {rnd, rnd_up, line_rnd, line_rnd_up} as the reference would hold them (vfgs_hw.c:52-55). */
 void vfgs_hip_get_seed_state(uint32_t out[4]);
 

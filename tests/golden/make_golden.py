@@ -57,10 +57,12 @@ def write_input(path, w, h, depth, fmt, nframes):
             f.write(fr.picture_bytes())
 
 
-def run_ref(w, h, depth, fmt, cfg, nframes, inp, out):
+def run_ref(w, h, depth, fmt, cfg, nframes, inp, out, outdepth=None):
     exe = "vfgs_ref" if fmt == "420" else "vfgs_ref_x"
     cmd = [str(T.REF_DIR / exe), "-w", str(w), "-h", str(h), "-b", str(depth), "-f", fmt,
            "-n", str(nframes), "-r", str(SEED)]
+    if outdepth:
+        cmd += ["--outdepth", str(outdepth)]
     if fmt != "420":
         cmd.append("--no-check")
     if cfg:
@@ -89,7 +91,7 @@ def main():
     (T.GOLDEN / "traces").mkdir(parents=True, exist_ok=True)
     (T.GOLDEN / "frames").mkdir(parents=True, exist_ok=True)
     cfgs = sorted(p.stem for p in CFG.glob("*.cfg"))
-    md5 = {"seed": SEED, "lcg_seed": 1, "small": {}, "inputs": {}, "full": {}}
+    md5 = {"seed": SEED, "lcg_seed": 1, "small": {}, "small_outdepth8": {}, "inputs": {}, "full": {}}
     w, h, n = SMALL
 
     with tempfile.TemporaryDirectory() as tmp:
@@ -113,6 +115,9 @@ def main():
                 per = w * h + 2 * (w // sx) * (h // sy)
                 np.savez_compressed(T.GOLDEN / "frames" / f"{name}_{w}x{h}.npz", out=raw[:per])  # first frame only
             print(name, md5["small"][name], flush=True)
+            # 10-bit in, 8-bit out (yuv_to_8bit, yuv.c:216-258) for the fused-output extension; stock CLI only (4:2:0)
+            if depth == 10 and fmt == "420" and cfg in ("fgs_sei", "fgs_afgs1_test1", "fgs_sei_ff_test6", "fgs_sei_ar_test1"):
+                md5["small_outdepth8"][name] = run_ref(w, h, depth, fmt, cfg, n, inputs[(depth, fmt)], out, outdepth=8)
 
         for name, fw, fh, depth, fmt, cfg, nf in FULL_SIZE:
             inp, out = f"{tmp}/full_in.yuv", f"{tmp}/full_out.yuv"

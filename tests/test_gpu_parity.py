@@ -247,3 +247,95 @@ def test_unchanged_reference_cli_linked_against_hip_library(hip, tmp_path):
         assert len(outs[0]) == len(inp.read_bytes())
         assert outs[0] != inp.read_bytes()          # grain was really added
         assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("name", sorted(MD5["small_outdepth8"]))
+def test_fused_8bit_output_matches_reference_outdepth8(hip, name):
+    """grain on 10-bit input with the 10->8 bit narrowing of yuv_to_8bit
+    (yuv.c:216-258) fused into the store; golden = reference CLI run with --outdepth 8."""
+    import hashlib
+    import torch
+    from gpu_util import DevFrame, stream_ptr
+    ora, (depth, sx, sy) = program(hip, name)
+    assert depth == 10
+    frames, _ = T.lcg_frames(W, H, depth, sx, sy, N)
+    m = hashlib.md5()
+    for f in frames:
+        want = f.copy()
+        ora.add_grain_frame(want)
+        src = DevFrame(f)
+        f8 = T.Frame(W, H, 8, sx, sy)
+        dY = torch.full(f8.Y.shape, 0x5a, dtype=torch.uint8, device="cuda")
+        dU = torch.full(f8.U.shape, 0x5a, dtype=torch.uint8, device="cuda")
+        dV = torch.full(f8.V.shape, 0x5a, dtype=torch.uint8, device="cuda")
+        hip.add_grain_copy8_dev(*src.ptrs(), dY.data_ptr(), dU.data_ptr(), dV.data_ptr(), W, H, 0, H, f.stride, f.cstride,
+                                f8.stride, f8.cstride, 1, 0, 0, 0, 0, stream_ptr())
+        torch.cuda.synchronize()
+        assert src.download().equal_all(f)
+        for got, w16, hh, ww in ((dY, want.Y, H, W), (dU, want.U, H // sy, W // sx), (dV, want.V, H // sy, W // sx)):
+            g = got.cpu().numpy()
+            exp = ((w16[:hh, :ww].astype(np.int32) + 2) >> 2).astype(np.uint8)
+            assert np.array_equal(g[:hh, :ww], exp)
+            m.update(g[:hh, :ww].tobytes())
+        assert (dY.cpu().numpy()[H:] == 0x5a).all()      # rows below the picture untouched
+        assert hip.seed_state() == ora.seed_state()
+    assert m.hexdigest() == MD5["small_outdepth8"][name]
+
+
+def test_fused_8bit_output_batch_and_parts_444(hip):
+    """copy8 with nframes > 1, a 16-aligned part, and 4:4:4 (16-sample chroma blocks)."""
+    import torch
+    from gpu_util import stream_ptr
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_ff_test6_10_444")
+    n, w, h = 3, 328, 176
+    frames, _ = T.lcg_frames(w, h, depth, sx, sy, n)
+    want = [f.copy() for f in frames]
+    for f in want:
+        ora.add_grain_frame(f)
+    f0 = frames[0]
+    f8 = T.Frame(w, h, 8, sx, sy)
+    Y = torch.from_numpy(np.stack([f.Y for f in frames]).view(np.uint8)).cuda()
+    U = torch.from_numpy(np.stack([f.U for f in frames]).view(np.uint8)).cuda()
+    V = torch.from_numpy(np.stack([f.V for f in frames]).view(np.uint8)).cuda()
+    dY = torch.zeros((n,) + f8.Y.shape, dtype=torch.uint8, device="cuda")
+    dU = torch.zeros((n,) + f8.U.shape, dtype=torch.uint8, device="cuda")
+    dV = torch.zeros((n,) + f8.V.shape, dtype=torch.uint8, device="cuda")
+    py, ph = 48, 96
+    sz = 2
+    hip.add_grain_copy8_dev(Y.data_ptr() + py * f0.stride * sz, U.data_ptr() + py * f0.cstride * sz, V.data_ptr() + py * f0.cstride * sz,
+                            dY.data_ptr() + py * f8.stride, dU.data_ptr() + py * f8.cstride, dV.data_ptr() + py * f8.cstride,
+                            w, h, py, ph, f0.stride, f0.cstride, f8.stride, f8.cstride, n,
+                            Y[0].numel(), U[0].numel(), dY[0].numel(), dU[0].numel(), stream_ptr())
+    torch.cuda.synchronize()
+    for i, wf in enumerate(want):
+        for got, w16 in ((dY[i], wf.Y), (dU[i], wf.U), (dV[i], wf.V)):
+            g = got.cpu().numpy()
+            exp = ((w16[py:py + ph, :w].astype(np.int32) + 2) >> 2).astype(np.uint8)
+            assert np.array_equal(g[py:py + ph, :w], exp)
+            assert (g[:py] == 0).all() and (g[py + ph:] == 0).all()
+    assert hip.seed_state() == ora.seed_state()
+
+
+def test_frames_part_batched_equals_whole(hip):
+    """What one rank of the multi-GPU bench runs: its stripe of several consecutive frames in ONE launch."""
+    import torch
+    from gpu_util import stream_ptr
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    n, w, h = 4, 640, 368
+    frames, _ = T.lcg_frames(w, h, depth, sx, sy, n)
+    want = [f.copy() for f in frames]
+    for f in want:
+        ora.add_grain_frame(f)
+    py, ph = 128, 112
+    f0 = frames[0]
+    Y = torch.from_numpy(np.stack([f.Y[py:py + ph] for f in frames]).view(np.uint8)).cuda()
+    U = torch.from_numpy(np.stack([f.U[py // 2:(py + ph) // 2] for f in frames]).view(np.uint8)).cuda()
+    V = torch.from_numpy(np.stack([f.V[py // 2:(py + ph) // 2] for f in frames]).view(np.uint8)).cuda()
+    hip.add_grain_frames_part_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, h, py, ph, f0.stride, f0.cstride, n,
+                                  Y[0].numel(), U[0].numel(), stream_ptr())
+    torch.cuda.synchronize()
+    for i, wf in enumerate(want):
+        assert np.array_equal(Y[i].cpu().numpy().view(wf.dtype).reshape(ph, -1), wf.Y[py:py + ph])
+        assert np.array_equal(U[i].cpu().numpy().view(wf.dtype).reshape(ph // 2, -1), wf.U[py // 2:(py + ph) // 2])
+        assert np.array_equal(V[i].cpu().numpy().view(wf.dtype).reshape(ph // 2, -1), wf.V[py // 2:(py + ph) // 2])
+    assert hip.seed_state() == ora.seed_state()

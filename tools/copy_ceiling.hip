@@ -85,6 +85,145 @@ __global__ void k_tiles(const uint8_t* src, uint8_t* dst, int pitch, int ntx, in
 	}
 }
 
+// ROWS rows x SEGS consecutive segments of `upt` 16-byte units per wave item
+template <int ROWS, int SEGS>
+__global__ void k_tiles_seg(const uint8_t* src, uint8_t* dst, int pitch, int ntx, int upt, int nrowgroups, int shift)
+{
+	const int wave = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int nwaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+	const int lane = threadIdx.x & 63;
+	for (int item = wave; item < ntx * nrowgroups; item += nwaves)
+	{
+		const int tx = item % ntx, rg = item / ntx;
+		u32x4 v[ROWS][SEGS];
+		bool ok[SEGS];
+		long off[SEGS];
+#pragma unroll
+		for (int g = 0; g < SEGS; g++)
+		{
+			off[g] = (long)((tx * SEGS + g) * upt + lane) * 16 - shift;
+			ok[g] = lane < upt && off[g] >= 0 && off[g] + 16 <= pitch;
+		}
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+#pragma unroll
+			for (int g = 0; g < SEGS; g++) if (ok[g]) v[r][g] = *(const u32x4*)(src + (size_t)(rg * ROWS + r) * pitch + off[g]);
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+#pragma unroll
+			for (int g = 0; g < SEGS; g++) if (ok[g]) *(u32x4*)(dst + (size_t)(rg * ROWS + r) * pitch + off[g]) = v[r][g] + 1u;
+	}
+}
+
+// the grain kernel's exact item: 4 luma rows x 62 units (shift 16 B) + U and V: 2 rows x 31 units (shift 8 B), 3 planes
+// CMODE 0: chroma 2 rows x 31 lanes per access;  1: chroma items cover 2 luma tiles: 1 row x 62 lanes per access, 2 accesses
+template <int CMODE>
+__global__ void k_item420(uint8_t* Y, uint8_t* U, uint8_t* V, int ypitch, int cpitch, int ntx, int nquads)
+{
+	typedef uint32_t v4a8 __attribute__((ext_vector_type(4), aligned(8)));
+	const int wave = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	const int nwaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+	const int lane = threadIdx.x & 63;
+	for (int item = wave; item < ntx * nquads; item += nwaves)
+	{
+		const int tx = item % ntx, q = item / ntx;
+		const long yoff = (long)(tx * 62 + lane) * 16 - 16;
+		const bool yok = lane < 62 && yoff >= 0 && yoff + 16 <= ypitch;
+		long coff; bool cok; int crow;
+		if (CMODE == 0) { coff = (long)(tx * 31 + (lane & 31)) * 16 - 8; cok = (lane & 31) < 31 && coff >= 0 && coff + 16 <= cpitch; crow = 2 * q + (lane >> 5); }
+		else { coff = (long)((tx & ~1) * 31 + lane) * 16 - 8; cok = lane < 62 && coff >= 0 && coff + 16 <= cpitch; crow = 2 * q + (tx & 1); }
+		u32x4 vy[4], vu, vv;
+#pragma unroll
+		for (int r = 0; r < 4; r++) if (yok) vy[r] = *(const u32x4*)(Y + (size_t)(4 * q + r) * ypitch + yoff);
+		if (cok) { vu = *(const v4a8*)(U + (size_t)crow * cpitch + coff); vv = *(const v4a8*)(V + (size_t)crow * cpitch + coff); }
+#pragma unroll
+		for (int r = 0; r < 4; r++) if (yok) *(u32x4*)(Y + (size_t)(4 * q + r) * ypitch + yoff) = vy[r] + 1u;
+		if (cok) { *(v4a8*)(U + (size_t)crow * cpitch + coff) = vu + 1u; *(v4a8*)(V + (size_t)crow * cpitch + coff) = vv + 1u; }
+	}
+}
+
+// branch-free (raw buffer ops, out-of-range lanes dropped by the hardware) versions of the tile shapes:
+// a wave item = ROWS rows x SEGS segments of `upt` 16-byte units, shifted by `shift` bytes; rows `pitch` apart
+template <int ROWS, int SEGS>
+__global__ void k_tiles_buf(uint8_t* buf, uint32_t bytes, int pitch, int ntx, int upt, int nrowgroups, int shift)
+{
+	const int wave = __builtin_amdgcn_readfirstlane((int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+	const int nwaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+	const int lane = threadIdx.x & 63;
+	__amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 0, (int)bytes, 0x00020000);
+	for (int item = wave; item < ntx * nrowgroups; item += nwaves)
+	{
+		const int tx = item % ntx, rg = item / ntx;
+		u32x4 v[ROWS][SEGS];
+		uint32_t off[ROWS][SEGS];
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+#pragma unroll
+			for (int g = 0; g < SEGS; g++)
+			{
+				const int x = ((tx * SEGS + g) * upt + lane) * 16 - shift;
+				const bool ok = lane < upt && x >= 0 && x + 16 <= pitch;
+				off[r][g] = ok ? (uint32_t)((rg * ROWS + r) * pitch + x) : 0x80000000u;
+				v[r][g] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[r][g], 0, 0);
+			}
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+#pragma unroll
+			for (int g = 0; g < SEGS; g++) __builtin_amdgcn_raw_buffer_store_b128(v[r][g] + 1u, rs, off[r][g], 0, 0);
+	}
+}
+
+// branch-free exact 4:2:0 items over three planes.  MODE 0: 4 luma rows x 62u + U,V as 2 rows x 31 lanes (8 B shift);
+// MODE 1: 2 luma rows x 2 x 62u + U,V as 1 row x 62 lanes
+template <int MODE>
+__global__ void k_item420_buf(uint8_t* Yb, uint32_t ybytes, uint8_t* Ub, uint8_t* Vb, uint32_t cbytes, int ypitch, int cpitch, int nblk2)
+{
+	const int wave = __builtin_amdgcn_readfirstlane((int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+	const int nwaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+	const int lane = threadIdx.x & 63;
+	__amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Yb, 0, (int)ybytes, 0x00020000);
+	__amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)Ub, 0, (int)cbytes, 0x00020000);
+	__amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)cbytes, 0x00020000);
+	const int ntx = MODE == 0 ? 16 : 8, ngroups = MODE == 0 ? 1080 : 2160;
+	for (int item = wave; item < ntx * ngroups; item += nwaves)
+	{
+		const int tx = item % ntx, q = item / ntx;
+		u32x4 vy[4], vu, vv;
+		uint32_t oy[4], oc;
+		if (MODE == 0)
+		{
+			const int x = (tx * 62 + lane) * 16 - 16;
+			const bool ok = lane < 62 && x >= 0 && x + 16 <= ypitch;
+#pragma unroll
+			for (int r = 0; r < 4; r++) oy[r] = ok ? (uint32_t)((4 * q + r) * ypitch + x) : 0x80000000u;
+			const int xc = (tx * 31 + (lane & 31)) * 16 - 8;
+			const bool okc = (lane & 31) < 31 && xc >= 0 && xc + 16 <= cpitch;
+			oc = okc ? (uint32_t)((2 * q + (lane >> 5)) * cpitch + xc) : 0x80000000u;
+		}
+		else
+		{
+#pragma unroll
+			for (int r = 0; r < 4; r++)
+			{
+				const int x = ((tx * 2 + (r & 1)) * 62 + lane) * 16 - 16;
+				const bool ok = lane < 62 && x >= 0 && x + 16 <= ypitch;
+				oy[r] = ok ? (uint32_t)((2 * q + (r >> 1)) * ypitch + x) : 0x80000000u;
+			}
+			const int xc = (tx * 62 + lane) * 16 - 8;
+			const bool okc = lane < 62 && xc >= 0 && xc + 16 <= cpitch;
+			oc = okc ? (uint32_t)(q * cpitch + xc) : 0x80000000u;
+		}
+#pragma unroll
+		for (int r = 0; r < 4; r++) vy[r] = __builtin_amdgcn_raw_buffer_load_b128(ry, oy[r], 0, 0);
+		vu = __builtin_amdgcn_raw_buffer_load_b128(ru, oc, 0, 0);
+		vv = __builtin_amdgcn_raw_buffer_load_b128(rv, oc, 0, 0);
+#pragma unroll
+		for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b128(vy[r] + 1u, ry, oy[r], 0, 0);
+		__builtin_amdgcn_raw_buffer_store_b128(vu + 1u, ru, oc, 0, 0);
+		__builtin_amdgcn_raw_buffer_store_b128(vv + 1u, rv, oc, 0, 0);
+	}
+}
+
 // chroma-shaped rows: 8-byte (not 16-byte) aligned 16-byte pieces, as one b128 or as two b64 accesses
 template <int ROWS, bool SPLIT>
 __global__ void k_tiles8(const uint8_t* src, uint8_t* dst, int pitch, int ntx, int upt, int nrowgroups)
@@ -162,6 +301,25 @@ int main()
 			run("tiles 64u aligned in-place", [&](int i) { k_tiles<4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 15, 64, rows / 4, 0); });
 			run("tiles 64u aligned out-of-place", [&](int i) { k_tiles<4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)b, pitch, 15, 64, rows / 4, 0); });
 			run("tiles 64u shift16 out-of-place", [&](int i) { k_tiles<4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)b, pitch, 16, 64, rows / 4, 16); });
+			run("tiles 2rows x 2x62u shift16 in-place", [&](int i) { k_tiles_seg<2, 2><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 8, 62, rows / 2, 16); });
+			run("tiles 1row x 4x62u shift16 in-place", [&](int i) { k_tiles_seg<1, 4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 4, 62, rows, 16); });
+			run("tiles 1row x 4x64u aligned in-place", [&](int i) { k_tiles_seg<1, 4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 4, 64, rows, 0); });
+			run("tiles 1row x 6x62u shift16 in-place", [&](int i) { k_tiles_seg<1, 6><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 3, 62, rows, 16); });
+			run("BUF tiles 4rows x 62u shift16", [&](int i) { k_tiles_buf<4, 1><<<blocks, threads>>>((uint8_t*)a[i], (uint32_t)bytes, pitch, 16, 62, rows / 4, 16); });
+			run("BUF tiles 4rows x 64u aligned", [&](int i) { k_tiles_buf<4, 1><<<blocks, threads>>>((uint8_t*)a[i], (uint32_t)bytes, pitch, 15, 64, rows / 4, 0); });
+			run("BUF tiles 6rows x 62u shift16", [&](int i) { k_tiles_buf<6, 1><<<blocks, threads>>>((uint8_t*)a[i], (uint32_t)bytes, pitch, 16, 62, rows / 6, 16); });
+			run("BUF tiles 2rows x 2x62u shift16", [&](int i) { k_tiles_buf<2, 2><<<blocks, threads>>>((uint8_t*)a[i], (uint32_t)bytes, pitch, 8, 62, rows / 2, 16); });
+			run("BUF tiles 1row x 4x62u shift16", [&](int i) { k_tiles_buf<1, 4><<<blocks, threads>>>((uint8_t*)a[i], (uint32_t)bytes, pitch, 4, 62, rows, 16); });
+			run("BUF tiles 1row x 4x64u aligned", [&](int i) { k_tiles_buf<1, 4><<<blocks, threads>>>((uint8_t*)a[i], (uint32_t)bytes, pitch, 4, 64, rows, 0); });
+			run("BUF tiles 1row x 6x62u shift16", [&](int i) { k_tiles_buf<1, 6><<<blocks, threads>>>((uint8_t*)a[i], (uint32_t)bytes, pitch, 3, 62, rows, 16); });
+			run("BUF item420 MODE0 (4Y x 62u, UV 2x31)", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;
+				k_item420_buf<0><<<blocks, threads>>>(Yp, 15360u * 4320u, Up, Vp, 7680u * 2160u, 15360, 7680, 0); });
+			run("BUF item420 MODE1 (2Y x 2x62u, UV 1x62)", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;
+				k_item420_buf<1><<<blocks, threads>>>(Yp, 15360u * 4320u, Up, Vp, 7680u * 2160u, 15360, 7680, 0); });
+			run("item420 (4Y rows + U,V 2x31) in-place", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;
+				k_item420<0><<<blocks, threads>>>(Yp, Up, Vp, 15360, 7680, 16, 1080); });
+			run("item420 chroma 1x62 per tile pair in-place", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;
+				k_item420<1><<<blocks, threads>>>(Yp, Up, Vp, 15360, 7680, 16, 1080); });
 			run("tiles 62u shift8 b128 in-place", [&](int i) { k_tiles8<4, false><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 16, 62, rows / 4); });
 			run("tiles 62u shift8 2xb64 in-place", [&](int i) { k_tiles8<4, true><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)a[i], pitch, 16, 62, rows / 4); });
 			run("tiles 60u aligned-ish out-of-place", [&](int i) { k_tiles<4><<<blocks, threads>>>((uint8_t*)a[i], (uint8_t*)b, pitch, 16, 60, rows / 4, 0); });

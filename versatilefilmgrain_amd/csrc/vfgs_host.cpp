@@ -18,7 +18,7 @@
 #include "vfgs_layout.h"
 
 namespace vfgs {
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, int grid, hipStream_t stream);
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, int grid, hipStream_t stream);
 int table_bytes(int csubx, int csuby);
 }
 
@@ -388,14 +388,31 @@ int check_geometry(const State& s, const void* dY, const void* dU, const void* d
 }
 
 // Core: launch the kernel over `nframes` frames, lines [part_y, part_y+part_h) of each.
+struct DstGeom {          // destination geometry when it differs from the source's (8-bit output of a 10-bit path)
+	bool out8 = false;
+	unsigned stride = 0, cstride = 0;
+	uint64_t ypitch = 0, cpitch = 0;
+};
+
 int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV, unsigned width,
                unsigned frame_y, unsigned frame_h, unsigned part_y, unsigned part_h, unsigned stride, unsigned cstride,
-               unsigned nframes, uint64_t ypitch, uint64_t cpitch, hipStream_t stream)
+               unsigned nframes, uint64_t ypitch, uint64_t cpitch, hipStream_t stream, DstGeom dg = DstGeom())
 {
 	State& s = S();
 	if (int e = ensure_init(-1)) return e;
-	if (int e = check_geometry(s, dY, dU, dV, width, stride, cstride)) return e;
 	if (int e = check_geometry(s, sY, sU, sV, width, stride, cstride)) return e;
+	if (!dg.out8)
+	{
+		if (int e = check_geometry(s, dY, dU, dV, width, stride, cstride)) return e;
+	}
+	else
+	{
+		const unsigned nb = (width + 15) / 16;
+		if (s.bs != 2) return fail(16, "8-bit output needs a 10-bit path (vfgs_set_depth(10))");
+		if (dg.stride < nb * 16 || dg.cstride < nb * 16 / s.csubx) return fail(6, "destination stride too small");
+		if ((((uintptr_t)dY | (uintptr_t)dU | (uintptr_t)dV) & 15) || dg.stride % 16 || dg.cstride % 16 || (dg.ypitch | dg.cpitch) % 16)
+			return fail(8, "destination planes, pitches and frame pitches must be multiples of 16 bytes");
+	}
 	if (part_h == 0 || nframes == 0) return 0;
 
 	const unsigned nblk = (width + 15) / 16;
@@ -408,6 +425,12 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.Y = (const uint8_t*)sY; a.U = (const uint8_t*)sU; a.V = (const uint8_t*)sV;
 	a.dY = (uint8_t*)dY; a.dU = (uint8_t*)dU; a.dV = (uint8_t*)dV;
 	a.y_extent = (uint32_t)yext; a.c_extent = (uint32_t)cext;
+	a.dy_extent = dg.out8 ? (uint32_t)((uint64_t)part_h * dg.stride) : a.y_extent;
+	a.dc_extent = dg.out8 ? (uint32_t)(crows * dg.cstride) : a.c_extent;
+	a.dy_frame_pitch = dg.out8 ? dg.ypitch : ypitch;
+	a.dc_frame_pitch = dg.out8 ? dg.cpitch : cpitch;
+	a.dstride = dg.out8 ? (int)dg.stride : (int)stride;
+	a.dcstride = dg.out8 ? (int)dg.cstride : (int)cstride;
 	a.y_frame_pitch = ypitch; a.c_frame_pitch = cpitch;
 	a.y0 = (int)part_y; a.nlines = (int)part_h;
 	a.nblk = (int)nblk;
@@ -449,7 +472,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.nitems = (int)total;
 	// persistent workgroups: at most kWGPerCU per CU, each loops over the items round-robin
 	const int grid = (int)std::min<long>((total + vfgs::kWavesPerWG - 1) / vfgs::kWavesPerWG, (long)s.cu_count * vfgs::kWGPerCU);
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, grid, stream));
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, grid, stream));
 	return 0;
 }
 
@@ -687,6 +710,24 @@ int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, 
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(sY, sU, sV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
 	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
+}
+
+int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV,
+                                 unsigned width, unsigned frame_height, unsigned part_y, unsigned part_height,
+                                 unsigned stride, unsigned cstride, unsigned dst_stride, unsigned dst_cstride,
+                                 unsigned nframes, uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes,
+                                 uint64_t dst_y_frame_pitch_bytes, uint64_t dst_c_frame_pitch_bytes, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
+	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
+	DstGeom dg;
+	dg.out8 = true;
+	dg.stride = dst_stride; dg.cstride = dst_cstride;
+	dg.ypitch = dst_y_frame_pitch_bytes; dg.cpitch = dst_c_frame_pitch_bytes;
+	return run_device(sY, sU, sV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
+	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream, dg);
 }
 
 void vfgs_hip_get_seed_state(uint32_t out[4])

@@ -134,13 +134,13 @@ __device__ __forceinline__ void load_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v0
 	{
 		if (!SPLIT)
 		{
-			const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, v0, soff, 0);
+			const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, v0, soff, VFGS_LDAUX);
 			w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
 		}
 		else
 		{
-			const u32x2 t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, v0, soff, 0);
-			const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, v1, soff, 0);
+			const u32x2 t0 = __builtin_amdgcn_raw_buffer_load_b64(rs, v0, soff, VFGS_LDAUX);
+			const u32x2 t1 = __builtin_amdgcn_raw_buffer_load_b64(rs, v1, soff, VFGS_LDAUX);
 			w[0] = t0.x; w[1] = t0.y; w[2] = t1.x; w[3] = t1.y;
 		}
 	}
@@ -149,13 +149,13 @@ __device__ __forceinline__ void load_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v0
 		uint32_t r0, r1;
 		if (!SPLIT)
 		{
-			const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, v0, soff, 0);
+			const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, v0, soff, VFGS_LDAUX);
 			r0 = t.x; r1 = t.y;
 		}
 		else
 		{
-			r0 = __builtin_amdgcn_raw_buffer_load_b32(rs, v0, soff, 0);
-			r1 = __builtin_amdgcn_raw_buffer_load_b32(rs, v1, soff, 0);
+			r0 = __builtin_amdgcn_raw_buffer_load_b32(rs, v0, soff, VFGS_LDAUX);
+			r1 = __builtin_amdgcn_raw_buffer_load_b32(rs, v1, soff, VFGS_LDAUX);
 		}
 		w[0] = __builtin_amdgcn_perm(0, r0, 0x0c010c00);
 		w[1] = __builtin_amdgcn_perm(0, r0, 0x0c030c02);
@@ -175,13 +175,13 @@ __device__ __forceinline__ void store_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v
 		if (!SPLIT)
 		{
 			const u32x4 t = {w[0], w[1], w[2], w[3]};
-			__builtin_amdgcn_raw_buffer_store_b128(t, rs, v0, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b128(t, rs, v0, soff, VFGS_STAUX);
 		}
 		else
 		{
 			const u32x2 t0 = {w[0], w[1]}, t1 = {w[2], w[3]};
-			__builtin_amdgcn_raw_buffer_store_b64(t0, rs, v0, soff, 0);
-			__builtin_amdgcn_raw_buffer_store_b64(t1, rs, v1, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b64(t0, rs, v0, soff, VFGS_STAUX);
+			__builtin_amdgcn_raw_buffer_store_b64(t1, rs, v1, soff, VFGS_STAUX);
 		}
 	}
 	else
@@ -191,14 +191,26 @@ __device__ __forceinline__ void store_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v
 		if (!SPLIT)
 		{
 			const u32x2 t = {r0, r1};
-			__builtin_amdgcn_raw_buffer_store_b64(t, rs, v0, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b64(t, rs, v0, soff, VFGS_STAUX);
 		}
 		else
 		{
-			__builtin_amdgcn_raw_buffer_store_b32(r0, rs, v0, soff, 0);
-			__builtin_amdgcn_raw_buffer_store_b32(r1, rs, v1, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(r0, rs, v0, soff, VFGS_STAUX);
+			__builtin_amdgcn_raw_buffer_store_b32(r1, rs, v1, soff, VFGS_STAUX);
 		}
 	}
+}
+
+// Fused output narrowing (the step after the path in the reference CLI, yuv_to_8bit,
+// yuv.c:216-258: out8 = (uint8)((v + 2) >> 2)): 10-bit results are stored as 8-bit samples.
+template <bool SPLIT>
+__device__ __forceinline__ void store_unit_narrow(__amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t v1, const uint32_t (&w)[4])
+{
+	uint32_t n[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		n[k] = ((w[k] + 0x00020002u) >> 2) & 0x00ff00ffu;     // both halves <= 1022: no carry across the halves
+	store_unit<8, SPLIT>(rs, v0, v1, 0, n);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -328,7 +340,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 // in one 16-byte access.
 enum { LOAD_Y = 0, LOAD_C = 1, COMP_Y = 2, COMP_C = 3 };
 
-template <int DEPTH, int CSUBX, int CSUBY, bool SPLITC, int PHASE>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool SPLITC, int PHASE>
 __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds, const int item, const int lane,
                                         uint32_t (&wy)[4][4], uint32_t (&wu)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4],
                                         uint32_t (&wv)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4],
@@ -376,8 +388,8 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 		// one descriptor per plane of this frame's stripe; num_records = its exact extent, so the
 		// hardware bounds-checks every access of the item
 		const __amdgpu_buffer_rsrc_t sY = make_rsrc(a.Y + (uint64_t)f * a.y_frame_pitch, a.y_extent);
-		const __amdgpu_buffer_rsrc_t dY = make_rsrc(a.dY + (uint64_t)f * a.y_frame_pitch, a.y_extent);
-		uint32_t voy[4];
+		const __amdgpu_buffer_rsrc_t dY = make_rsrc(a.dY + (uint64_t)f * a.dy_frame_pitch, a.dy_extent);
+		uint32_t voy[4], dvo[4];
 #pragma unroll
 		for (int r = 0; r < 4; r++)
 		{
@@ -385,6 +397,7 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 			const bool rok = (yabs >= a.y0) && (yabs < a.y0 + a.nlines);          // wave-uniform
 			// a line outside the stripe is computed but neither read nor written (all lanes out of range)
 			voy[r] = (rok && l_ok) ? (uint32_t)(yabs - a.y0) * yrow + (uint32_t)(8 * ju * SZ) : kOOB;
+			dvo[r] = !OUT8 ? voy[r] : ((rok && l_ok) ? (uint32_t)(yabs - a.y0) * (uint32_t)a.dstride + (uint32_t)(8 * ju) : kOOB);
 			if (PHASE == LOAD_Y) load_unit<DEPTH, false>(sY, voy[r], 0, 0, wy[r]);
 		}
 		if (PHASE == LOAD_Y)
@@ -415,7 +428,8 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 				                              ycur.sign * wc, ycur.sign * wc,
 				                              ubase + rowoff, ubase + rowoff + 4 * kSlots, yup.sign * wu_, yup.sign * wu_,
 				                              edge_on, l_first, 1, 2, 2, a.scale_shift, half, ylo2, yhi2);
-				store_unit<DEPTH, false>(dY, voy[r], 0, 0, wy[r]);
+				if (OUT8) store_unit_narrow<false>(dY, dvo[r], 0, wy[r]);
+				else      store_unit<DEPTH, false>(dY, dvo[r], 0, 0, wy[r]);
 			}
 		}
 		const int rel = __mul24(ycur.sign, swap_lane_pairs(ycur.sign));    // relative sign of the two blocks at the edge
@@ -430,16 +444,17 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 			grain_unit<DEPTH, false, true>(lds, wy[r], luts, luts, base + rowoff, base + rowoff + 4 * kSlots,
 			                               0, 0, 0, 0, 0, 0,
 			                               edge_on, l_first, rel, cs, cs, a.scale_shift, half, ylo2, yhi2);
-			store_unit<DEPTH, false>(dY, voy[r], 0, 0, wy[r]);
+			if (OUT8) store_unit_narrow<false>(dY, dvo[r], 0, wy[r]);
+			else      store_unit<DEPTH, false>(dY, dvo[r], 0, 0, wy[r]);
 		}
 	}
 	else
 	{
 		const __amdgpu_buffer_rsrc_t sU = make_rsrc(a.U + (uint64_t)f * a.c_frame_pitch, a.c_extent);
 		const __amdgpu_buffer_rsrc_t sV = make_rsrc(a.V + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-		const __amdgpu_buffer_rsrc_t dU = make_rsrc(a.dU + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-		const __amdgpu_buffer_rsrc_t dV = make_rsrc(a.dV + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-		uint32_t cv0[CNL], cv1[CNL];
+		const __amdgpu_buffer_rsrc_t dU = make_rsrc(a.dU + (uint64_t)f * a.dc_frame_pitch, a.dc_extent);
+		const __amdgpu_buffer_rsrc_t dV = make_rsrc(a.dV + (uint64_t)f * a.dc_frame_pitch, a.dc_extent);
+		uint32_t cv0[CNL], cv1[CNL], dc0[CNL], dc1[CNL];
 		int crl[CNL];                                  // chroma row inside the block row, per access
 		int cm;                                        // CBW == 8: block edge index m; CBW == 16: unit index
 		bool c_first = false;
@@ -471,6 +486,9 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 			const uint32_t rowb = (uint32_t)(prow - a.y0 / CSUBY) * crow;
 			cv0[c] = (rok && h0) ? rowb + (uint32_t)(xc0 * SZ) : kOOB;
 			cv1[c] = (rok && h1) ? rowb + (uint32_t)((xc0 + 4) * SZ) : kOOB;
+			const uint32_t drowb = (uint32_t)(prow - a.y0 / CSUBY) * (uint32_t)a.dcstride;
+			dc0[c] = !OUT8 ? cv0[c] : ((rok && h0) ? drowb + (uint32_t)xc0 : kOOB);
+			dc1[c] = !OUT8 ? cv1[c] : ((rok && h1) ? drowb + (uint32_t)(xc0 + 4) : kOOB);
 			if (PHASE == LOAD_C)
 			{
 				load_unit<DEPTH, SPLIT>(sU, cv0[c], cv1[c], 0, wu[c]);
@@ -564,13 +582,21 @@ __device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds,
 				grain_unit<DEPTH, false, CBW == 16>(lds, wv[c], lutv0, lutv1, va0, va1, 0, 0, 0, 0, 0, 0,
 				                                    edge_on, c_first, relv, rv0, rv1, a.scale_shift, half, clo2, chi2);
 			}
-			store_unit<DEPTH, SPLIT>(dU, cv0[c], cv1[c], 0, wu[c]);
-			store_unit<DEPTH, SPLIT>(dV, cv0[c], cv1[c], 0, wv[c]);
+			if (OUT8)
+			{
+				store_unit_narrow<SPLIT>(dU, dc0[c], dc1[c], wu[c]);
+				store_unit_narrow<SPLIT>(dV, dc0[c], dc1[c], wv[c]);
+			}
+			else
+			{
+				store_unit<DEPTH, SPLIT>(dU, dc0[c], dc1[c], 0, wu[c]);
+				store_unit<DEPTH, SPLIT>(dV, dc0[c], dc1[c], 0, wv[c]);
+			}
 		}
 	}
 }
 
-template <int DEPTH, int CSUBX, int CSUBY>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
 __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4) void grain_kernel(const KernelArgs a)
 {
 	using L = TableLayout<CSUBX, CSUBY>;
@@ -615,8 +641,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4)
 	uint32_t sy[2][2], sc[4][2];      // raw LFSR stream dwords of the item's blocks (luma / chroma; current, upper row)
 #define VFGS_PHASE(PH, IT)                                                                                      \
 	do {                                                                                                        \
-		if (is_split(IT)) do_item<DEPTH, CSUBX, CSUBY, true, PH>(a, lds, IT, lane, wy, wu, wv, sy, sc);        \
-		else              do_item<DEPTH, CSUBX, CSUBY, false, PH>(a, lds, IT, lane, wy, wu, wv, sy, sc);       \
+		if (is_split(IT)) do_item<DEPTH, CSUBX, CSUBY, OUT8, true, PH>(a, lds, IT, lane, wy, wu, wv, sy, sc);  \
+		else              do_item<DEPTH, CSUBX, CSUBY, OUT8, false, PH>(a, lds, IT, lane, wy, wu, wv, sy, sc); \
 	} while (0)
 
 #if VFGS_PIPE
@@ -648,19 +674,22 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4)
 // ---------------------------------------------------------------------------------------
 // host-side launcher (called from vfgs_host.cpp)
 
-template <int DEPTH, int CSUBX, int CSUBY>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
 static hipError_t launch_t(const KernelArgs& a, int grid, hipStream_t stream)
 {
-	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY>), dim3(grid), dim3(kWavesPerWG * 64), 0, stream, a);
+	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY, OUT8>), dim3(grid), dim3(kWavesPerWG * 64), 0, stream, a);
 	return hipGetLastError();
 }
 
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, int grid, hipStream_t stream)
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, int grid, hipStream_t stream)
 {
-#define VFGS_CASE(D, X, Y) if (depth == D && csubx == X && csuby == Y) return launch_t<D, X, Y>(a, grid, stream)
+#define VFGS_CASE(D, X, Y) if (depth == D && csubx == X && csuby == Y && !out8) return launch_t<D, X, Y, false>(a, grid, stream)
 	VFGS_CASE(10, 2, 2); VFGS_CASE(10, 2, 1); VFGS_CASE(10, 1, 1); VFGS_CASE(10, 1, 2);
 	VFGS_CASE(8, 2, 2);  VFGS_CASE(8, 2, 1);  VFGS_CASE(8, 1, 1);  VFGS_CASE(8, 1, 2);
 #undef VFGS_CASE
+#define VFGS_CASE8(X, Y) if (depth == 10 && csubx == X && csuby == Y && out8) return launch_t<10, X, Y, true>(a, grid, stream)
+	VFGS_CASE8(2, 2); VFGS_CASE8(2, 1); VFGS_CASE8(1, 1); VFGS_CASE8(1, 2);
+#undef VFGS_CASE8
 	return hipErrorInvalidValue;
 }
 

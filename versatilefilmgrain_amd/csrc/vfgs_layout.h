@@ -14,6 +14,12 @@ constexpr int kMaxUnits = 64;    // 8-sample units per work item row (one per la
 #ifndef VFGS_WG_PER_CU
 #define VFGS_WG_PER_CU 2
 #endif
+#ifndef VFGS_LDAUX
+#define VFGS_LDAUX 0      // cache policy bits of the sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef VFGS_STAUX
+#define VFGS_STAUX 0      // cache policy bits of the sample stores
+#endif
 #ifndef VFGS_CHUNKED
 #define VFGS_CHUNKED 0    // 1: every workgroup gets one contiguous run of items instead of round-robin
 #endif
@@ -69,6 +75,10 @@ struct KernelArgs {
 	uint32_t c_extent;        // bytes of one frame's chroma stripe, per plane
 	uint64_t y_frame_pitch;   // bytes from frame f to frame f+1 (batched launches)
 	uint64_t c_frame_pitch;
+	// destination geometry; identical to the source's unless the output is narrowed to 8 bit
+	uint32_t dy_extent, dc_extent;
+	uint64_t dy_frame_pitch, dc_frame_pitch;
+	int dstride, dcstride;    // samples
 	const uint32_t* stream;   // LFSR bit stream cache (device), bit m = word[m>>5] >> (m&31)
 	const uint8_t* tables;    // TableLayout image (device)
 	uint32_t cur_bit0;        // stream bit of the register of block 0, first block row of the stripe, frame 0

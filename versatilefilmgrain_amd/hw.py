@@ -48,6 +48,8 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_add_grain_frames_dev.argtypes = [vp, vp, vp, u, u, u, u, u, C.c_uint64, C.c_uint64, vp]
     lib.vfgs_hip_add_grain_frames_part_dev.argtypes = [vp, vp, vp, u, u, u, u, u, u, u, C.c_uint64, C.c_uint64, vp]
     lib.vfgs_hip_add_grain_copy_dev.argtypes = [vp, vp, vp, vp, vp, vp, u, u, u, u, u, u, u, C.c_uint64, C.c_uint64, vp]
+    lib.vfgs_hip_add_grain_copy8_dev.argtypes = [vp, vp, vp, vp, vp, vp, u, u, u, u, u, u, u, u, u,
+                                                 C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     lib.vfgs_hip_get_seed_state.argtypes = [vp]
     lib.vfgs_hip_last_error_string.restype = C.c_char_p
     lib.vfgs_hip_timer_begin.argtypes = [vp]
@@ -66,7 +68,7 @@ EXPORTS = [
     "vfgs_add_grain_stripe", "vfgs_hip_init", "vfgs_hip_shutdown", "vfgs_hip_reset_state",
     "vfgs_hip_add_grain_stripe_dev", "vfgs_hip_add_grain_frame_dev", "vfgs_hip_add_grain_frame_part_dev",
     "vfgs_hip_add_grain_frames_dev", "vfgs_hip_add_grain_frames_part_dev", "vfgs_hip_add_grain_copy_dev",
-    "vfgs_hip_get_seed_state", "vfgs_hip_last_error",
+    "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
 ]
 
@@ -131,6 +133,12 @@ class VfgsHip:
                            nframes, ypitch, cpitch, stream=0):
         self._ck(self.lib.vfgs_hip_add_grain_copy_dev(sY, sU, sV, dY, dU, dV, width, frame_height, part_y, part_height,
                                                       stride, cstride, nframes, ypitch, cpitch, stream))
+
+    def add_grain_copy8_dev(self, sY, sU, sV, dY, dU, dV, width, frame_height, part_y, part_height, stride, cstride,
+                            dstride, dcstride, nframes, ypitch, cpitch, dypitch, dcpitch, stream=0):
+        self._ck(self.lib.vfgs_hip_add_grain_copy8_dev(sY, sU, sV, dY, dU, dV, width, frame_height, part_y, part_height,
+                                                       stride, cstride, dstride, dcstride, nframes, ypitch, cpitch,
+                                                       dypitch, dcpitch, stream))
 
     def seed_state(self):
         out = (C.c_uint32 * 4)()
