@@ -339,3 +339,62 @@ def test_frames_part_batched_equals_whole(hip):
         assert np.array_equal(U[i].cpu().numpy().view(wf.dtype).reshape(ph // 2, -1), wf.U[py // 2:(py + ph) // 2])
         assert np.array_equal(V[i].cpu().numpy().view(wf.dtype).reshape(ph // 2, -1), wf.V[py // 2:(py + ph) // 2])
     assert hip.seed_state() == ora.seed_state()
+
+
+def _line_loop(hwimpl, fr, sy):
+    for y in range(fr.height):
+        hwimpl.add_grain_line(fr.Y[y].ctypes.data, fr.U[y // sy].ctypes.data, fr.V[y // sy].ctypes.data, y, fr.width)
+
+
+@pytest.mark.parametrize("name,w,h", [("fgs_sei_10_420", 192, 144), ("fgs_sei_10_420", 200, 150), ("fgs_afgs1_test1_8_444", 192, 144),
+                                       ("fgs_sei_ff_test6_8_422", 264, 136), ("fgs_sei_10_420", 1920, 1080)])
+def test_line_api_lookahead_many_frames(hip, name, w, h):
+    """The drop-in loop of vfgs_main.c:664-682 over several frames: from the second call on the
+    library serves lines from pre-computed stripes (line_call() in vfgs_host.cpp); results and seed
+    registers must be those of the oracle called line by line."""
+    ora, (depth, sx, sy) = program(hip, name)
+    nfr = 2 if w > 1000 else 4
+    frames, _ = T.lcg_frames(w, h, depth, sx, sy, nfr, garbage_padding=True)
+    for f in frames:
+        a, b = f.copy(), f.copy()
+        _line_loop(hip, a, sy)
+        _line_loop(ora, b, sy)
+        assert a.equal_all(b)
+        assert hip.seed_state() == ora.seed_state()
+
+
+def test_line_api_lookahead_sees_late_changes_and_irregular_calls(hip):
+    """Look-ahead must never be observable: the caller edits lines it has not handed over yet,
+    skips lines, repeats a line, changes the width, calls a setter in the middle of a frame."""
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    frames, _ = T.lcg_frames(320, 176, depth, sx, sy, 3)
+    rng = np.random.default_rng(5)
+    for fi, f in enumerate(frames):
+        a, b = f.copy(), f.copy()
+        y = 0
+        while y < f.height:
+            for fr, hwimpl in ((a, hip), (b, ora)):
+                hwimpl.add_grain_line(fr.Y[y].ctypes.data, fr.U[y // 2].ctypes.data, fr.V[y // 2].ctypes.data, y, fr.width)
+            assert np.array_equal(a.Y[y], b.Y[y]) and np.array_equal(a.U[y // 2], b.U[y // 2]), (fi, y)
+            if y % 23 == 5 and y + 3 < f.height:          # edit a line that was (probably) read ahead already
+                patch = rng.integers(0, 1024, f.width).astype(a.dtype)
+                a.Y[y + 2, :f.width] = patch
+                b.Y[y + 2, :f.width] = patch
+                a.V[(y + 2) // 2, :16] = 7
+                b.V[(y + 2) // 2, :16] = 7
+            if fi == 1 and y == 40:                        # repeat a line
+                for fr, hwimpl in ((a, hip), (b, ora)):
+                    hwimpl.add_grain_line(fr.Y[y].ctypes.data, fr.U[y // 2].ctypes.data, fr.V[y // 2].ctypes.data, y, fr.width)
+            if fi == 1 and y == 70:                        # skip ahead
+                y += 5
+            if fi == 2 and y == 50:                        # a setter in the middle of the frame
+                hip.set_scale_shift(3)
+                ora.set_scale_shift(3)
+            if fi == 2 and y == 90:                        # narrower calls from here on
+                for yy in range(y + 1, y + 4):
+                    for fr, hwimpl in ((a, hip), (b, ora)):
+                        hwimpl.add_grain_line(fr.Y[yy].ctypes.data, fr.U[yy // 2].ctypes.data, fr.V[yy // 2].ctypes.data, yy, 200)
+                y += 3
+            y += 1
+        assert a.equal_all(b)
+        assert hip.seed_state() == ora.seed_state()

@@ -5,6 +5,9 @@
 // no CPU implementation of the grain path in this library.
 #include <hip/hip_runtime.h>
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -237,6 +240,27 @@ struct State {
 	size_t stage_cap[3] = {0, 0, 0};
 	hipStream_t own_stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+	// ---- look-ahead of the line API (see line_call()) -----------------------------------
+	uint64_t gen = 0;                 // bumped by every call that changes state other than a line call
+	struct LineAhead {
+		bool enabled = true;
+		// call pattern learned from consecutive line calls
+		bool have_prev = false;
+		const uint8_t *pY = nullptr, *pU = nullptr, *pV = nullptr;
+		unsigned py = 0, pwidth = 0;
+		ptrdiff_t ypitch = 0, cpitch = 0;     // host row pitches in bytes, 0 = not yet known
+		unsigned frame_h = 0;                 // picture height, 0 = not yet known
+		// one pre-computed stripe
+		bool valid = false;
+		uint64_t gen = 0;
+		unsigned y0 = 0, n = 0, next = 0, width = 0, crow0 = 0;
+		const uint8_t *Y0 = nullptr, *U0 = nullptr, *V0 = nullptr;
+		uint8_t* in[3] = {nullptr, nullptr, nullptr};    // pinned: what was read from the caller's lines
+		uint8_t* out[3] = {nullptr, nullptr, nullptr};   // pinned: their results
+		size_t cap[3] = {0, 0, 0};
+		unsigned rowlen[3] = {0, 0, 0}, dpitch[3] = {0, 0, 0};
+	} la;
 
 	State()
 	{
@@ -515,6 +539,176 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// vfgs_add_grain_line with look-ahead.
+//
+// The drop-in call hands over ONE line and must be complete on return, which costs a full
+// H2D + launch + D2H + sync (~90 us) per line.  The reference's frame loop (vfgs_main.c:664-682)
+// however walks a frame that is already complete in host memory, top to bottom, with fixed
+// row pitches.  So once the pitches are known from two consecutive calls, a miss computes the
+// stripe [y, y+n) in one round trip from the lines the caller has NOT handed over yet, keeps
+// their inputs and results in pinned buffers, and writes back only line y.  A later call that
+// is exactly the predicted next line (same y, pointers, width, no state change in between) and
+// whose input bytes still equal what was read ahead is served by a memcpy; anything else drops
+// the stripe and recomputes.  Lines the caller has not handed over are never written, the seed
+// registers advance per call exactly as before, so the observable behaviour is unchanged.
+// Until the picture height is known (first frame) the look-ahead stops at the end of the
+// 16-line block row and is guarded by mincore(); VFGS_HIP_LINE_LOOKAHEAD=0 disables it.
+
+constexpr unsigned kMaxAhead = 256;
+
+bool mapped(const void* p, size_t len)
+{
+	const uintptr_t ps = (uintptr_t)sysconf(_SC_PAGESIZE);
+	const uintptr_t a = (uintptr_t)p & ~(ps - 1);
+	const size_t l = (((uintptr_t)p + len - a) + ps - 1) & ~(ps - 1);
+	std::vector<unsigned char> v(l / ps + 1);
+	return mincore((void*)a, l, v.data()) == 0;
+}
+
+int line_speculate(State& s, void* Y, void* U, void* V, unsigned y, unsigned width, unsigned n)
+{
+	State::LineAhead& la = s.la;
+	const unsigned sz = s.bs ? 2 : 1;
+	const unsigned nblk = (width + 15) / 16;
+	const unsigned crow0 = y / s.csuby;
+	const unsigned crows = (y + n - 1) / s.csuby - crow0 + 1;
+	const unsigned rows[3] = {n, crows, crows};
+	const size_t spitch[3] = {(size_t)la.ypitch, (size_t)la.cpitch, (size_t)la.cpitch};
+	const uint8_t* host[3] = {(const uint8_t*)Y, (const uint8_t*)U, (const uint8_t*)V};
+	for (int i = 0; i < 3; i++)
+	{
+		la.rowlen[i] = (i ? nblk * 16 / s.csubx : nblk * 16) * sz;
+		la.dpitch[i] = (la.rowlen[i] + 255) & ~255u;
+		const size_t need = (size_t)la.dpitch[i] * rows[i] + 256;
+		if (la.cap[i] < need)
+		{
+			if (la.in[i]) HIP_TRY(hipHostFree(la.in[i]));
+			if (la.out[i]) HIP_TRY(hipHostFree(la.out[i]));
+			la.in[i] = la.out[i] = nullptr; la.cap[i] = 0;
+			HIP_TRY(hipHostMalloc((void**)&la.in[i], need, hipHostMallocDefault));
+			HIP_TRY(hipHostMalloc((void**)&la.out[i], need, hipHostMallocDefault));
+			la.cap[i] = need;
+		}
+		if (s.stage_cap[i] < need)
+		{
+			if (s.stage[i]) HIP_TRY(hipFree(s.stage[i]));
+			s.stage[i] = nullptr; s.stage_cap[i] = 0;
+			HIP_TRY(hipMalloc(&s.stage[i], need));
+			s.stage_cap[i] = need;
+		}
+		for (unsigned r = 0; r < rows[i]; r++)   // snapshot of the caller's lines (also the H2D source)
+			memcpy(la.in[i] + (size_t)r * la.dpitch[i], host[i] + (size_t)r * spitch[i], la.rowlen[i]);
+		HIP_TRY(hipMemcpyAsync(s.stage[i], la.in[i], (size_t)la.dpitch[i] * rows[i], hipMemcpyHostToDevice, s.own_stream));
+	}
+	// seeds: the stripe is computed from the current registers, but only line y is committed now
+	const uint64_t r0 = s.rnd, r1 = s.rnd_up, r2 = s.line_rnd, r3 = s.line_rnd_up;
+	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], s.stage[0], s.stage[1], s.stage[2], width, y, n, y, n,
+	                       la.dpitch[0] / sz, la.dpitch[1] / sz, 1, 0, 0, s.own_stream))
+		return e;
+	s.rnd = r0; s.rnd_up = r1; s.line_rnd = r2; s.line_rnd_up = r3;
+	advance_seeds(s, y, 1, nblk, y);
+	for (int i = 0; i < 3; i++)
+		HIP_TRY(hipMemcpyAsync(la.out[i], s.stage[i], (size_t)la.dpitch[i] * rows[i], hipMemcpyDeviceToHost, s.own_stream));
+	HIP_TRY(hipStreamSynchronize(s.own_stream));
+	// hand back line y only
+	memcpy(Y, la.out[0], la.rowlen[0]);
+	if (y % s.csuby == 0)
+	{
+		memcpy(U, la.out[1], la.rowlen[1]);
+		memcpy(V, la.out[2], la.rowlen[2]);
+	}
+	la.valid = n > 1;
+	la.gen = s.gen;
+	la.y0 = y; la.n = n; la.next = y + 1; la.width = width; la.crow0 = crow0;
+	la.Y0 = host[0]; la.U0 = host[1]; la.V0 = host[2];
+	return 0;
+}
+
+int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
+{
+	State& s = S();
+	if (int e = ensure_init(-1)) return e;
+	State::LineAhead& la = s.la;
+	static const bool env_on = [] { const char* e = getenv("VFGS_HIP_LINE_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+	if (!la.enabled || !env_on)
+		return run_host(Y, U, V, y, width, 1, 0, 0);
+
+	const uint8_t *cY = (const uint8_t*)Y, *cU = (const uint8_t*)U, *cV = (const uint8_t*)V;
+	const unsigned nblk = (width + 15) / 16;
+	int rc = -1;
+
+	// 1. served from the pre-computed stripe?
+	if (la.valid)
+	{
+		const unsigned k = y - la.y0;
+		const size_t crow = (size_t)(y / s.csuby - la.crow0);
+		const bool predicted = la.gen == s.gen && y == la.next && width == la.width &&
+		                       cY == la.Y0 + (ptrdiff_t)k * la.ypitch &&
+		                       cU == la.U0 + (ptrdiff_t)crow * la.cpitch && cV == la.V0 + (ptrdiff_t)crow * la.cpitch;
+		const bool chroma = (y % s.csuby) == 0;
+		if (predicted && !memcmp(cY, la.in[0] + (size_t)k * la.dpitch[0], la.rowlen[0]) &&
+		    (!chroma || (!memcmp(cU, la.in[1] + crow * la.dpitch[1], la.rowlen[1]) &&
+		                 !memcmp(cV, la.in[2] + crow * la.dpitch[2], la.rowlen[2]))))
+		{
+			memcpy(Y, la.out[0] + (size_t)k * la.dpitch[0], la.rowlen[0]);
+			if (chroma)
+			{
+				memcpy(U, la.out[1] + crow * la.dpitch[1], la.rowlen[1]);
+				memcpy(V, la.out[2] + crow * la.dpitch[2], la.rowlen[2]);
+			}
+			advance_seeds(s, y, 1, nblk, y);
+			la.next = y + 1;
+			if (la.next == la.y0 + la.n)
+				la.valid = false;
+			rc = 0;
+		}
+		else
+			la.valid = false;
+	}
+
+	if (rc != 0)
+	{
+		// 2. learn the caller's walk from consecutive calls (vfgs_main.c:675-680)
+		if (la.have_prev && y == la.py + 1 && width == la.pwidth)
+		{
+			la.ypitch = cY - la.pY;
+			if (s.csuby == 1 || (la.py & 1))
+			{
+				const ptrdiff_t du = cU - la.pU, dv = cV - la.pV;
+				la.cpitch = (du == dv) ? du : 0;
+			}
+			else if (cU != la.pU || cV != la.pV)
+				la.cpitch = 0, la.ypitch = 0;     // not the reference's walk: no look-ahead
+		}
+		else if (la.have_prev && y == 0 && la.py > 0 && width == la.pwidth)
+			la.frame_h = la.py + 1;               // wrapped around: the previous frame had py + 1 lines
+		else if (la.have_prev)
+			la.ypitch = la.cpitch = 0, la.frame_h = 0;
+
+		// 3. compute: this line alone, or this line plus the lines the caller is about to hand over
+		unsigned n = 1;
+		const unsigned sz = s.bs ? 2 : 1;
+		const size_t ylen = (size_t)nblk * 16 * sz, clen = (size_t)nblk * 16 / s.csubx * sz;
+		if (la.ypitch >= (ptrdiff_t)ylen && la.cpitch >= (ptrdiff_t)clen && width > 128)
+		{
+			const unsigned limit = (la.frame_h > y) ? la.frame_h : ((y | 15) + 1);
+			n = std::min(limit - y, kMaxAhead);
+			if (n > 1 && la.frame_h <= y)     // height still unknown: never read unmapped memory
+			{
+				const size_t crows = (y + n - 1) / s.csuby - y / s.csuby + 1;
+				if (!mapped(cY, (size_t)(n - 1) * la.ypitch + ylen) || !mapped(cU, (crows - 1) * la.cpitch + clen) ||
+				    !mapped(cV, (crows - 1) * la.cpitch + clen))
+					n = 1;
+			}
+		}
+		rc = (n > 1) ? line_speculate(s, Y, U, V, y, width, n) : run_host(Y, U, V, y, width, 1, 0, 0);
+	}
+	la.have_prev = true;
+	la.pY = cY; la.pU = cU; la.pV = cV; la.py = y; la.pwidth = width;
+	return rc;
+}
+
 }  // namespace
 
 // ========================================================================================
@@ -525,6 +719,7 @@ extern "C" {
 void vfgs_set_luma_pattern(int index, signed char* P)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_luma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:316)"); }
 	memcpy(S().bank[0][index], P, 64 * 64);   // vfgs_hw.c:317
 	S().tables_dirty = true;
@@ -533,6 +728,7 @@ void vfgs_set_luma_pattern(int index, signed char* P)
 void vfgs_set_chroma_pattern(int index, signed char* P)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	State& s = S();
 	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_chroma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:322)"); }
 	for (int i = 0; i < 64 / s.csuby; i++)   // vfgs_hw.c:323-324: pitch from csuby, length from csubx
@@ -543,6 +739,7 @@ void vfgs_set_chroma_pattern(int index, signed char* P)
 void vfgs_set_scale_lut(int c, unsigned char lut[])
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (c < 0 || c > 2) { fail(21, "vfgs_set_scale_lut: component %d", c); die("bad component (vfgs_hw.c:329)"); }
 	memcpy(S().slut[c], lut, 256);
 	S().tables_dirty = true;
@@ -551,6 +748,7 @@ void vfgs_set_scale_lut(int c, unsigned char lut[])
 void vfgs_set_pattern_lut(int c, unsigned char lut[])
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (c < 0 || c > 2) { fail(21, "vfgs_set_pattern_lut: component %d", c); die("bad component (vfgs_hw.c:335)"); }
 	memcpy(S().plut[c], lut, 256);
 	S().tables_dirty = true;
@@ -559,6 +757,7 @@ void vfgs_set_pattern_lut(int c, unsigned char lut[])
 void vfgs_set_seed(unsigned int seed)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	State& s = S();
 	s.lfsr.reseed(seed << 1);   // vfgs_hw.c:343
 	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
@@ -567,6 +766,7 @@ void vfgs_set_seed(unsigned int seed)
 void vfgs_set_scale_shift(int shift)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (shift < 2 || shift >= 8) { fail(22, "vfgs_set_scale_shift: %d", shift); die("shift out of 2..7 (vfgs_hw.c:348)"); }
 	S().scale_shift = shift + 6 - S().bs;   // vfgs_hw.c:349
 }
@@ -574,6 +774,7 @@ void vfgs_set_scale_shift(int shift)
 void vfgs_set_depth(int depth)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	State& s = S();
 	if (depth != 8 && depth != 10) { fail(23, "vfgs_set_depth: %d", depth); die("depth must be 8 or 10 (vfgs_hw.c:354)"); }
 	s.scale_shift += s.bs - (depth - 8);     // vfgs_hw.c:356-359
@@ -583,6 +784,7 @@ void vfgs_set_depth(int depth)
 void vfgs_set_legal_range(int legal)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	State& s = S();
 	s.ymin = s.cmin = legal ? 16 : 0;        // vfgs_hw.c:366-378
 	s.ymax = legal ? 235 : 255;
@@ -592,6 +794,7 @@ void vfgs_set_legal_range(int legal)
 void vfgs_set_chroma_subsampling(int subx, int suby)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if ((subx != 1 && subx != 2) || (suby != 1 && suby != 2)) { fail(24, "vfgs_set_chroma_subsampling: %d,%d", subx, suby); die("subsampling must be 1 or 2 (vfgs_hw.c:384-385)"); }
 	S().csubx = subx;
 	S().csuby = suby;
@@ -601,14 +804,14 @@ void vfgs_set_chroma_subsampling(int subx, int suby)
 void vfgs_add_grain_line(void* Y, void* U, void* V, int y, int width)
 {
 	std::lock_guard<std::mutex> g(g_mu);
-	// a line call carries no pitch: a 1-line stripe never uses it
-	if (run_host(Y, U, V, (unsigned)y, (unsigned)width, 1, 0, 0))
+	if (line_call(Y, U, V, (unsigned)y, (unsigned)width))
 		die("vfgs_add_grain_line");
 }
 
 void vfgs_add_grain_stripe(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (run_host(Y, U, V, y, width, height, stride, cstride))
 		die("vfgs_add_grain_stripe");
 }
@@ -616,6 +819,7 @@ void vfgs_add_grain_stripe(void* Y, void* U, void* V, unsigned y, unsigned width
 void vfgs_hip_reset_state(void)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	State& s = S();
 	memset(s.bank, 0, sizeof s.bank);
 	memset(s.slut, 0, sizeof s.slut);
@@ -645,6 +849,13 @@ void vfgs_hip_shutdown(void)
 	s.tables_ring.release();
 	s.lfsr.release();
 	for (int i = 0; i < 3; i++) { if (s.stage[i]) (void)hipFree(s.stage[i]); s.stage[i] = nullptr; s.stage_cap[i] = 0; }
+	for (int i = 0; i < 3; i++)
+	{
+		if (s.la.in[i]) (void)hipHostFree(s.la.in[i]);
+		if (s.la.out[i]) (void)hipHostFree(s.la.out[i]);
+		s.la.in[i] = s.la.out[i] = nullptr; s.la.cap[i] = 0;
+	}
+	s.la.valid = false;
 	if (s.own_stream) (void)hipStreamDestroy(s.own_stream);
 	if (s.ev0) (void)hipEventDestroy(s.ev0);
 	if (s.ev1) (void)hipEventDestroy(s.ev1);
@@ -657,6 +868,7 @@ int vfgs_hip_add_grain_stripe_dev(void* dY, void* dU, void* dV, unsigned y, unsi
                                   unsigned stride, unsigned cstride, void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	return run_device(dY, dU, dV, dY, dU, dV, width, y, height, y, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
 }
 
@@ -664,6 +876,7 @@ int vfgs_hip_add_grain_frame_dev(void* dY, void* dU, void* dV, unsigned width, u
                                  unsigned stride, unsigned cstride, void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, height, 0, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
 }
 
@@ -671,6 +884,7 @@ int vfgs_hip_add_grain_frame_part_dev(void* dY, void* dU, void* dV, unsigned wid
                                       unsigned part_y, unsigned part_height, unsigned stride, unsigned cstride, void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
 	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
@@ -681,6 +895,7 @@ int vfgs_hip_add_grain_frames_dev(void* dY, void* dU, void* dV, unsigned width, 
                                   uint64_t c_frame_pitch_bytes, void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, height, 0, height, stride, cstride, nframes,
 	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
@@ -692,6 +907,7 @@ int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned wi
                                        void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
 	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
@@ -705,6 +921,7 @@ int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, 
                                 uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes, void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
 	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
@@ -719,6 +936,7 @@ int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV,
                                  uint64_t dst_y_frame_pitch_bytes, uint64_t dst_c_frame_pitch_bytes, void* stream)
 {
 	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
 	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
