@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per launch per rank (a step = gpus*batch frames)")
     ap.add_argument("--pool", type=int, default=4, help="distinct step-sized buffer sets cycled through (total >> 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="developer option: run the N-rank code path with all ranks on cuda:0 and gloo instead of RCCL")
     args = ap.parse_args()
 
     import torch
@@ -109,10 +111,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     h = hw.VfgsHip(device=local)
     T.replay(h, T.load_trace(TRACE))     # programs banks/LUTs/shift/depth/subsampling/seed 12345
@@ -156,7 +163,7 @@ def main():
     barrier()
     launch_ms = ev0.elapsed_time(ev1) / args.steps     # same stream as the kernels (torch's current stream)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
