@@ -27,9 +27,15 @@ GB = 199.0656e6 / 1e3
 def build(variant, tmp):
     parts = variant.split(",")
     out = Path(tmp) / f"libvfgs_{abs(hash(variant))}.so"
+    src = ROOT / "versatilefilmgrain_amd/csrc"
+    flags = []
+    for x in parts[1:]:
+        if x.startswith("src="):           # alternative source directory (e.g. an older kernel kept for A/B runs)
+            src = ROOT / x[4:]
+        else:
+            flags.append(x)
     cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-w", f"-DVFGS_ABLATE={parts[0]}",
-           *parts[1:], "-o", str(out), str(ROOT / "versatilefilmgrain_amd/csrc/vfgs_kernel.hip"),
-           str(ROOT / "versatilefilmgrain_amd/csrc/vfgs_host.cpp")]
+           *flags, f"-I{ROOT / 'versatilefilmgrain_amd/csrc'}", "-o", str(out), str(src / "vfgs_kernel.hip"), str(src / "vfgs_host.cpp")]
     subprocess.run(cmd, check=True, cwd=tmp)
     return out
 

@@ -224,6 +224,63 @@ __global__ void k_item420_buf(uint8_t* Yb, uint32_t ybytes, uint8_t* Ub, uint8_t
 	}
 }
 
+// plane-specialised items: every item is ONE row x 4 consecutive segments of 62 units in ONE plane
+// (luma rows shifted 16 B, chroma rows shifted 8 B); item order: all Y rows, then U rows, then V rows, or interleaved per row group
+template <int ORDER>
+__global__ void k_item_planes(uint8_t* Yb, uint32_t ybytes, uint8_t* Ub, uint8_t* Vb, uint32_t cbytes, int ypitch, int cpitch)
+{
+	const int wave = __builtin_amdgcn_readfirstlane((int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+	const int nwaves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+	const int lane = threadIdx.x & 63;
+	__amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)Yb, 0, (int)ybytes, 0x00020000);
+	__amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)Ub, 0, (int)cbytes, 0x00020000);
+	__amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (int)cbytes, 0x00020000);
+	const int yitems = 4320 * 4, citems = 2160 * 2;
+	for (int item = wave; item < yitems + 2 * citems; item += nwaves)
+	{
+		int plane, row, tx;
+		if (ORDER == 0)
+		{
+			if (item < yitems) { plane = 0; row = item / 4; tx = item % 4; }
+			else if (item < yitems + citems) { plane = 1; row = (item - yitems) / 2; tx = (item - yitems) % 2; }
+			else { plane = 2; row = (item - yitems - citems) / 2; tx = (item - yitems - citems) % 2; }
+		}
+		else
+		{   // per luma row pair: 8 Y items, 2 U items, 2 V items
+			const int g = item / 12, k = item % 12;
+			if (k < 8) { plane = 0; row = 2 * g + k / 4; tx = k % 4; }
+			else if (k < 10) { plane = 1; row = g; tx = k - 8; }
+			else { plane = 2; row = g; tx = k - 10; }
+		}
+		const int pitch = plane ? cpitch : ypitch, shift = plane ? 8 : 16;
+		u32x4 v[4];
+		uint32_t off[4];
+#pragma unroll
+		for (int g = 0; g < 4; g++)
+		{
+			const int x = ((tx * 4 + g) * 62 + lane) * 16 - shift;
+			const bool ok = lane < 62 && x >= 0 && x + 16 <= pitch;
+			off[g] = ok ? (uint32_t)(row * pitch + x) : 0x80000000u;
+		}
+		if (plane == 0) {
+#pragma unroll
+			for (int g = 0; g < 4; g++) v[g] = __builtin_amdgcn_raw_buffer_load_b128(ry, off[g], 0, 0);
+#pragma unroll
+			for (int g = 0; g < 4; g++) __builtin_amdgcn_raw_buffer_store_b128(v[g] + 1u, ry, off[g], 0, 0);
+		} else if (plane == 1) {
+#pragma unroll
+			for (int g = 0; g < 4; g++) v[g] = __builtin_amdgcn_raw_buffer_load_b128(ru, off[g], 0, 0);
+#pragma unroll
+			for (int g = 0; g < 4; g++) __builtin_amdgcn_raw_buffer_store_b128(v[g] + 1u, ru, off[g], 0, 0);
+		} else {
+#pragma unroll
+			for (int g = 0; g < 4; g++) v[g] = __builtin_amdgcn_raw_buffer_load_b128(rv, off[g], 0, 0);
+#pragma unroll
+			for (int g = 0; g < 4; g++) __builtin_amdgcn_raw_buffer_store_b128(v[g] + 1u, rv, off[g], 0, 0);
+		}
+	}
+}
+
 // chroma-shaped rows: 8-byte (not 16-byte) aligned 16-byte pieces, as one b128 or as two b64 accesses
 template <int ROWS, bool SPLIT>
 __global__ void k_tiles8(const uint8_t* src, uint8_t* dst, int pitch, int ntx, int upt, int nrowgroups)
@@ -316,6 +373,10 @@ int main()
 				k_item420_buf<0><<<blocks, threads>>>(Yp, 15360u * 4320u, Up, Vp, 7680u * 2160u, 15360, 7680, 0); });
 			run("BUF item420 MODE1 (2Y x 2x62u, UV 1x62)", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;
 				k_item420_buf<1><<<blocks, threads>>>(Yp, 15360u * 4320u, Up, Vp, 7680u * 2160u, 15360, 7680, 0); });
+			run("BUF plane items 1row x 4x62u, planes in turn", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;
+				k_item_planes<0><<<blocks, threads>>>(Yp, 15360u * 4320u, Up, Vp, 7680u * 2160u, 15360, 7680); });
+			run("BUF plane items 1row x 4x62u, interleaved", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;
+				k_item_planes<1><<<blocks, threads>>>(Yp, 15360u * 4320u, Up, Vp, 7680u * 2160u, 15360, 7680); });
 			run("item420 (4Y rows + U,V 2x31) in-place", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;
 				k_item420<0><<<blocks, threads>>>(Yp, Up, Vp, 15360, 7680, 16, 1080); });
 			run("item420 chroma 1x62 per tile pair in-place", [&](int i) { uint8_t* Yp = (uint8_t*)a[i]; uint8_t* Up = Yp + (size_t)15360 * 4320; uint8_t* Vp = Up + (size_t)7680 * 2160;

@@ -458,12 +458,29 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.y_frame_pitch = ypitch; a.c_frame_pitch = cpitch;
 	a.y0 = (int)part_y; a.nlines = (int)part_h;
 	a.nblk = (int)nblk;
-	// units of 8 samples per row incl. the (invalid) one left of the picture: 2*nblk + 1; split
-	// into the fewest tiles of at most 64 units, all of the same even length (vfgs_kernel.hip)
-	const unsigned tunits = 2 * nblk + 1;
-	a.ntx = (int)((tunits + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits);
-	a.upt = (int)(2 * ((tunits + 2 * a.ntx - 1) / (2 * a.ntx)));
-	a.nbr = (int)(((part_y + part_h - 1) >> 4) - (part_y >> 4) + 1);
+	// planes with 16-sample blocks: 2*nblk + 1 units of 8 samples per row incl. the (invalid) one
+	// left of the picture, in the fewest segments of at most 64 units, all of the same even length
+	{
+		const unsigned tunits = 2 * nblk + 1;
+		a.segs_y = (int)((tunits + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits);
+		a.upt_y = (int)(2 * ((tunits + 2 * a.segs_y - 1) / (2 * a.segs_y)));
+		a.tiles_y = (a.segs_y + 3) / 4;
+		if (s.csubx == 2)
+		{   // 8-sample chroma blocks: one lane per block edge m = 0 .. nblk
+			const unsigned tedges = nblk + 1;
+			a.segs_c = (int)((tedges + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits);
+			a.upt_c = (int)((tedges + a.segs_c - 1) / a.segs_c);
+			a.tiles_c = (a.segs_c + 3) / 4;
+		}
+		else { a.segs_c = a.segs_y; a.upt_c = a.upt_y; a.tiles_c = a.tiles_y; }
+		a.crow_first = (int)((part_y + s.csuby - 1) / s.csuby);
+		a.ncrows = (int)((part_y + part_h + s.csuby - 1) / s.csuby) - a.crow_first;
+		a.items_y = (int)part_h * a.tiles_y;
+		a.items_c = a.ncrows * a.tiles_c;
+		a.lut_off = (uint32_t)(vfgs::table_bytes(s.csubx, s.csuby) - 3 * 2 * 256 * 4);
+		a.chroma_off = 64u * (64 * vfgs::kSlots + 16);
+	}
+	const int nbr_stripe = (int)(((part_y + part_h - 1) >> 4) - (part_y >> 4) + 1);
 	a.stride = (int)stride; a.cstride = (int)cstride;
 	a.nframes = (int)nframes;
 	a.scale_shift = s.scale_shift;
@@ -480,7 +497,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		if (f >= 2 && p.cur0 != first_cur + (second_cur - first_cur) * f)
 			return fail(10, "internal: batch seed positions are not equidistant");
 		lo = std::min(lo, std::min(p.cur0, p.up0));
-		hi = std::max(hi, p.cur0 + (uint64_t)a.nbr * nblk);
+		hi = std::max(hi, p.cur0 + (uint64_t)nbr_stripe * nblk);
 		hi = std::max(hi, p.up0 + nblk);
 	}
 	if (int e = upload_tables(s, stream)) return e;
@@ -491,7 +508,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.up_bit0 = (uint32_t)(first_up - s.lfsr.base_bit());
 	a.frame_bit_step = nframes > 1 ? (uint32_t)(second_cur - first_cur) : 0;
 
-	const long total = (long)a.nbr * 4 * a.ntx * a.nframes;
+	const long total = ((long)a.items_y + 2L * a.items_c) * a.nframes;
 	if (total > 0x7fffffffL) return fail(14, "launch too large");
 	a.nitems = (int)total;
 	// persistent workgroups: at most kWGPerCU per CU, each loops over the items round-robin

@@ -23,9 +23,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "vfgs_layout.h"
 
 namespace vfgs {
+
+struct TableLayoutBase { static constexpr int LUMA_OFF = 0; };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -320,279 +324,184 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 }
 
 // ---------------------------------------------------------------------------------------
-// Geometry of one work item along x.
+// Work items.
 //
-// A row of nblk grain blocks is cut into "units" of 8 samples: unit j covers luma samples
+// A row of nblk grain blocks is cut into "units" of 8 samples: unit j covers samples
 // [8j, 8j+8), j = 0 .. 2*nblk-1; even j = first half of block j/2, odd j = second half of block
-// (j-1)/2.  The pair (odd j, j+1) straddles the edge between two blocks and always stays in
-// one item: item tx owns units [tx*L - 1, tx*L - 1 + L), L even (a.upt), lane i <-> unit tx*L-1+i.
-// Subsampled chroma (8-sample blocks): one lane owns the 8 chroma samples around block edge
-// m, i.e. the second half of block m-1 and the first half of block m; 32 lanes per row.
+// (j-1)/2.  The pair (odd j, j+1) straddles the edge between two blocks and always stays in one
+// wave access ("segment"): segment s owns units [s*upt - 1, s*upt - 1 + upt), upt even, lane i
+// <-> unit s*upt - 1 + i.  Planes with 8-sample blocks (subsampled chroma): one lane owns the 8
+// samples around block edge m, i.e. the second half of block m-1 and the first half of block m;
+// segment s owns edges [s*upt, s*upt + upt).
+//
+// One work item = ONE row of ONE plane x 4 consecutive segments (<= 4 KiB contiguous), owned by
+// one wavefront.  A wave therefore streams from one plane in long runs (the 16-/8-byte shifted
+// segment ends produce two partial cache lines per run instead of two per segment), the overlap
+// decision (lines j = 0, 1 of a block row) is wave-uniform, and the three planes need no common
+// tile geometry.  Items of a frame are numbered Y rows first, then Cb rows, then Cr rows.
 
-// One work item (see "Geometry" above), in four phases so that the kernel can interleave two
-// items: LOAD_Y / LOAD_C issue the global loads of the luma / chroma rows into registers,
-// COMP_Y / COMP_C compute and store them.  The kernel's order per item is
-//     LOAD_C(i), COMP_Y(i), LOAD_Y(i+1), COMP_C(i)
-// so a wave always has loads in flight while it computes, with no more registers than one
-// item's worth of data (the luma registers are refilled as soon as they have been stored).
-// SPLITC = the item touches the left or right picture edge, where a subsampled-chroma lane can
-// own only one valid half: those items move chroma in two 8-byte halves per lane, all others
-// in one 16-byte access.
-enum { LOAD_Y = 0, LOAD_C = 1, COMP_Y = 2, COMP_C = 3 };
-
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool SPLITC, int PHASE>
-__device__ __forceinline__ void do_item(const KernelArgs& a, const uint8_t* lds, const int item, const int lane,
-                                        uint32_t (&wy)[4][4], uint32_t (&wu)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4],
-                                        uint32_t (&wv)[(4 / CSUBY) / ((CSUBX == 1) ? 1 : 2)][4],
-                                        uint32_t (&sy)[2][2], uint32_t (&sc)[4][2])
+// vfgs_hw.c:99-138 with the component as wave-uniform data: the x field is 10 bits at `sx`, the
+// y field the low 10 bits of the register rotated right by `sy` (component 1 takes bits 31:24
+// and 1:0 -- exactly a rotation by 24), the sign bit at `sb`.
+template <int SUBX, int SUBY, int RS>
+__device__ __forceinline__ BlockParam block_param_rt(uint32_t v, uint32_t bank_off, int sx, int sy, int sb)
 {
-	using L = TableLayout<CSUBX, CSUBY>;
-	constexpr int SZ = DEPTH > 8 ? 2 : 1;
-	constexpr int CBW = 16 / CSUBX;               // chroma block width in samples
-	constexpr int CROWS = 4 / CSUBY;              // chroma rows per item (4 luma lines)
-	constexpr int CRPL = (CBW == 16) ? 1 : 2;     // chroma rows per wave access
-	constexpr int CNL = CROWS / CRPL;             // chroma accesses per plane per item
-	constexpr uint32_t LUTY = L::LUT_OFF, LUTU = L::LUT_OFF + 2048, LUTV = L::LUT_OFF + 4096;   // [+scale | -scale] each
-	constexpr bool SPLIT = SPLITC && (CBW != 16);
-	constexpr bool LUMA = (PHASE == LOAD_Y || PHASE == COMP_Y);
-	constexpr bool COMP = (PHASE == COMP_Y || PHASE == COMP_C);
+	const uint32_t fx = (v >> sx) & 0x3ff;
+	const uint32_t fy = __builtin_amdgcn_alignbit(v, v, sy) & 0x3ff;
+	const uint32_t ox = (__umul24(fx, 13u) >> 10) * (4 / SUBX);
+	const uint32_t oy = (__umul24(fy, 12u) >> 10) * (4 / SUBY);
+	BlockParam r;
+	r.addr = __umul24(oy, (uint32_t)RS) + ox * kSlots + bank_off;
+	r.sign = ((v >> sb) & 1) ? -1 : 1;
+	return r;
+}
 
+struct ItemDesc {   // all wave-uniform
+	int f;       // frame of the batch
+	int plane;   // 0 = Y, 1 = Cb, 2 = Cr
+	int row;     // absolute row of that plane
+	int tile;    // group of 4 segments along the row
+};
+
+// PHASE 0 issues the item's global loads (samples into w, one dword per lane of the LFSR stream
+// slices of the item's block row into sw); PHASE 1 computes and stores.
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, bool SPLITC, int PHASE>
+__device__ __forceinline__ void plane_item(const KernelArgs& a, uint8_t* lds, uint32_t scratch, const ItemDesc d, const int lane,
+                                           uint32_t (&w)[4][4], uint32_t (&sw)[2])
+{
+	constexpr int SZ = DEPTH > 8 ? 2 : 1;
+	constexpr bool SPLIT = SPLITC && (BW != 16);
+	const bool luma = (d.plane == 0);
 	const int nunits = 2 * a.nblk;
 	const int last = a.nblk - 1;
-	const int half = 1 << (a.scale_shift - 1);
+	const int upt = (BW == 16) ? a.upt_y : a.upt_c;
+	const int segs = (BW == 16) ? a.segs_y : a.segs_c;
 
-	// item -> (frame f, block row k of the stripe, line quad p, tile tx); tx fastest
-	int t = item;
-	const int tx = t % a.ntx; t /= a.ntx;
-	const int p = t & 3;      t >>= 2;
-	const int k = t % a.nbr;
-	const int f = t / a.nbr;
-	const int R = (a.y0 >> 4) + k;                // absolute block row (y >> 4)
-	const bool has_up = (R > 0) && (p == 0);      // lines j = 0, 1 of a block row below the first (vfgs_hw.c:175,180)
+	// wave-uniform row data
+	const int y = d.row * SUBY;                        // luma line this row belongs to
+	const int R = y >> 4;                              // block row
+	const int jrow = y & 15;
+	const int rloc = d.row & (16 / SUBY - 1);          // row inside the block row
+	const bool has_up = (R > 0) && (jrow <= 1);        // vfgs_hw.c:175,180
+	const int k = R - (a.y0 >> 4);                     // block row inside the stripe
+	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)d.f * a.frame_bit_step + (uint32_t)(k * a.nblk);
+	const uint32_t up_bit = (k > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)d.f * a.frame_bit_step;
+	const uint32_t cur_w0 = cur_bit >> 5, up_w0 = up_bit >> 5;
 
-	// whole item outside the stripe (only for stripes that are not multiples of 16 lines)?
-	if (COMP && (16 * R + 4 * p + 3 < a.y0 || 16 * R + 4 * p >= a.y0 + a.nlines))
-		return;
+	const uint32_t pitch = (uint32_t)((luma ? a.stride : a.cstride) * SZ);
+	const uint32_t dpitch = OUT8 ? (uint32_t)(luma ? a.dstride : a.dcstride) : pitch;
+	const int prow0 = luma ? a.y0 : a.y0 / SUBY;       // row the plane pointers address
+	const uint8_t* sbase = (luma ? a.Y : (d.plane == 1 ? a.U : a.V)) + (uint64_t)d.f * (luma ? a.y_frame_pitch : a.c_frame_pitch);
+	uint8_t* dbase = (luma ? a.dY : (d.plane == 1 ? a.dU : a.dV)) + (uint64_t)d.f * (luma ? a.dy_frame_pitch : a.dc_frame_pitch);
+	// num_records = exact extent of the plane's stripe: the hardware bounds-checks every access
+	const __amdgpu_buffer_rsrc_t srs = make_rsrc(sbase, luma ? a.y_extent : a.c_extent);
+	const __amdgpu_buffer_rsrc_t drs = make_rsrc(dbase, luma ? a.dy_extent : a.dc_extent);
+	const uint32_t rowb = (uint32_t)(d.row - prow0) * pitch, drowb = (uint32_t)(d.row - prow0) * dpitch;
 
-	const uint32_t yrow = (uint32_t)(a.stride * SZ), crow = (uint32_t)(a.cstride * SZ);
-	const int j0 = tx * a.upt - 1;                // first unit of this item
-	const int ju = j0 + lane;                     // this lane's unit (luma, and chroma when CBW == 16)
-	const bool l_ok = (lane < a.upt) && (ju >= 0) && (ju < nunits);
-	const bool l_first = !(ju & 1);               // first half of its block
-	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(k * a.nblk);
-	const uint32_t up_bit = (k > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
-	const int yblk = min(max(ju >> 1, 0), last);
-
-	if (LUMA)
+	// per-lane geometry of the 4 segments
+	uint32_t vo0[4], vo1[4], do0[4], do1[4];
+	int bl[4], br[4];            // blocks left / right of the lane's edge (BW == 16: both = the lane's block)
+	bool first[4], edge[4];
+#pragma unroll
+	for (int g = 0; g < 4; g++)
 	{
-		// one descriptor per plane of this frame's stripe; num_records = its exact extent, so the
-		// hardware bounds-checks every access of the item
-		const __amdgpu_buffer_rsrc_t sY = make_rsrc(a.Y + (uint64_t)f * a.y_frame_pitch, a.y_extent);
-		const __amdgpu_buffer_rsrc_t dY = make_rsrc(a.dY + (uint64_t)f * a.dy_frame_pitch, a.dy_extent);
-		uint32_t voy[4], dvo[4];
-#pragma unroll
-		for (int r = 0; r < 4; r++)
+		const int seg = d.tile * 4 + g;
+		const bool sok = (seg < segs) && (lane < upt);
+		if (BW == 16)
 		{
-			const int yabs = 16 * R + 4 * p + r;
-			const bool rok = (yabs >= a.y0) && (yabs < a.y0 + a.nlines);          // wave-uniform
-			// a line outside the stripe is computed but neither read nor written (all lanes out of range)
-			voy[r] = (rok && l_ok) ? (uint32_t)(yabs - a.y0) * yrow + (uint32_t)(8 * ju * SZ) : kOOB;
-			dvo[r] = !OUT8 ? voy[r] : ((rok && l_ok) ? (uint32_t)(yabs - a.y0) * (uint32_t)a.dstride + (uint32_t)(8 * ju) : kOOB);
-			if (PHASE == LOAD_Y) load_unit<DEPTH, false>(sY, voy[r], 0, 0, wy[r]);
+			const int ju = seg * upt - 1 + lane;
+			const bool ok = sok && (ju >= 0) && (ju < nunits);
+			first[g] = !(ju & 1);
+			bl[g] = br[g] = min(max(ju >> 1, 0), last);
+			const int jl = first[g] ? ju - 1 : ju;          // left unit of this lane pair
+			edge[g] = sok && (jl >= 0) && (jl + 1 < nunits);
+			vo0[g] = ok ? rowb + (uint32_t)(8 * ju * SZ) : kOOB;
+			vo1[g] = 0;
+			do0[g] = !OUT8 ? vo0[g] : (ok ? drowb + (uint32_t)(8 * ju) : kOOB);
+			do1[g] = 0;
 		}
-		if (PHASE == LOAD_Y)
+		else
 		{
-			stream_fetch(a.stream, cur_bit + yblk, sy[0]);
-			if (has_up) stream_fetch(a.stream, up_bit + yblk, sy[1]);
-			return;
-		}
-
-		const uint32_t ylo2 = (uint32_t)a.ylo * 0x10001u, yhi2 = (uint32_t)a.yhi * 0x10001u;
-		const uint32_t vy = stream_cut(sy[0], cur_bit + yblk);
-		const BlockParam ycur = block_param<0, 1, 1, L::LRS>(vy, L::LUMA_OFF);
-		// edge between this lane pair: left unit must exist (>= 0), right unit must exist (< nunits)
-		const int jl = l_first ? ju - 1 : ju;
-		const bool edge_on = (lane < a.upt) && (jl >= 0) && (jl + 1 < nunits);
-		const uint32_t hoff = l_first ? 0u : 8u * kSlots;
-		const uint32_t base = ycur.addr + hoff;
-		if (has_up)   // wave-uniform: lines 0 and 1 blend with the block row above
-		{
-			const BlockParam yup = block_param<0, 1, 1, L::LRS>(stream_cut(sy[1], up_bit + yblk), L::LUMA_OFF);
-			const uint32_t ubase = yup.addr + 16u * L::LRS + hoff;
-#pragma unroll
-			for (int r = 0; r < 2; r++)
-			{
-				const uint32_t rowoff = (uint32_t)(4 * p + r) * L::LRS;   // scalar
-				const int wc = (r == 0) ? 12 : 24, wu_ = (r == 0) ? 24 : 12;   // vfgs_hw.c:177-183, suby == 1
-				grain_unit<DEPTH, true, true>(lds, wy[r], LUTY, LUTY, base + rowoff, base + rowoff + 4 * kSlots,
-				                              ycur.sign * wc, ycur.sign * wc,
-				                              ubase + rowoff, ubase + rowoff + 4 * kSlots, yup.sign * wu_, yup.sign * wu_,
-				                              edge_on, l_first, 1, 2, 2, a.scale_shift, half, ylo2, yhi2);
-				if (OUT8) store_unit_narrow<false>(dY, dvo[r], 0, wy[r]);
-				else      store_unit<DEPTH, false>(dY, dvo[r], 0, 0, wy[r]);
-			}
-		}
-		const int rel = __mul24(ycur.sign, swap_lane_pairs(ycur.sign));    // relative sign of the two blocks at the edge
-		const uint32_t luts = LUTY + (ycur.sign < 0 ? 1024u : 0u);
-		const int cs = ycur.sign < 0 ? 1 : 2;
-#pragma unroll
-		for (int r = 0; r < 4; r++)
-		{
-			if (r < 2 && has_up)
-				continue;
-			const uint32_t rowoff = (uint32_t)(4 * p + r) * L::LRS;   // scalar
-			grain_unit<DEPTH, false, true>(lds, wy[r], luts, luts, base + rowoff, base + rowoff + 4 * kSlots,
-			                               0, 0, 0, 0, 0, 0,
-			                               edge_on, l_first, rel, cs, cs, a.scale_shift, half, ylo2, yhi2);
-			if (OUT8) store_unit_narrow<false>(dY, dvo[r], 0, wy[r]);
-			else      store_unit<DEPTH, false>(dY, dvo[r], 0, 0, wy[r]);
+			const int m = seg * upt + lane;                 // block edge index
+			const bool in = sok && (m <= a.nblk);
+			const bool h0 = in && (m - 1 >= 0), h1 = in && (m <= last);
+			first[g] = false;
+			bl[g] = min(max(m - 1, 0), last);
+			br[g] = min(m, last);
+			edge[g] = h0 && h1;
+			const int xc0 = 8 * m - 4;
+			vo0[g] = h0 ? rowb + (uint32_t)(xc0 * SZ) : kOOB;
+			vo1[g] = h1 ? rowb + (uint32_t)((xc0 + 4) * SZ) : kOOB;
+			if (!SPLIT && !(h0 && h1)) vo0[g] = kOOB;       // (cannot happen in a non-edge item)
+			do0[g] = !OUT8 ? vo0[g] : (h0 ? drowb + (uint32_t)xc0 : kOOB);
+			do1[g] = !OUT8 ? vo1[g] : (h1 ? drowb + (uint32_t)(xc0 + 4) : kOOB);
+			if (OUT8 && !SPLIT && !(h0 && h1)) do0[g] = kOOB;
 		}
 	}
-	else
-	{
-		const __amdgpu_buffer_rsrc_t sU = make_rsrc(a.U + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-		const __amdgpu_buffer_rsrc_t sV = make_rsrc(a.V + (uint64_t)f * a.c_frame_pitch, a.c_extent);
-		const __amdgpu_buffer_rsrc_t dU = make_rsrc(a.dU + (uint64_t)f * a.dc_frame_pitch, a.dc_extent);
-		const __amdgpu_buffer_rsrc_t dV = make_rsrc(a.dV + (uint64_t)f * a.dc_frame_pitch, a.dc_extent);
-		uint32_t cv0[CNL], cv1[CNL], dc0[CNL], dc1[CNL];
-		int crl[CNL];                                  // chroma row inside the block row, per access
-		int cm;                                        // CBW == 8: block edge index m; CBW == 16: unit index
-		bool c_first = false;
-		bool h0, h1;
-		int xc0;
-		if (CBW == 16)
-		{
-			cm = ju;
-			h0 = h1 = l_ok;
-			c_first = l_first;
-			xc0 = 8 * ju;
-		}
-		else
-		{
-			const int cu = lane & 31;
-			cm = (j0 + 1) / 2 + cu;
-			const bool in = cu < a.upt / 2;
-			h0 = in && (cm - 1 >= 0) && (cm - 1 <= last);
-			h1 = in && (cm <= last);
-			xc0 = 8 * cm - 4;
-		}
-#pragma unroll
-		for (int c = 0; c < CNL; c++)
-		{
-			crl[c] = CROWS * p + CRPL * c + ((CBW == 16) ? 0 : (lane >> 5));
-			const int prow = R * (16 / CSUBY) + crl[c];          // absolute chroma row
-			const int yabs = prow * CSUBY;
-			const bool rok = (yabs >= a.y0) && (yabs < a.y0 + a.nlines);
-			const uint32_t rowb = (uint32_t)(prow - a.y0 / CSUBY) * crow;
-			cv0[c] = (rok && h0) ? rowb + (uint32_t)(xc0 * SZ) : kOOB;
-			cv1[c] = (rok && h1) ? rowb + (uint32_t)((xc0 + 4) * SZ) : kOOB;
-			const uint32_t drowb = (uint32_t)(prow - a.y0 / CSUBY) * (uint32_t)a.dcstride;
-			dc0[c] = !OUT8 ? cv0[c] : ((rok && h0) ? drowb + (uint32_t)xc0 : kOOB);
-			dc1[c] = !OUT8 ? cv1[c] : ((rok && h1) ? drowb + (uint32_t)(xc0 + 4) : kOOB);
-			if (PHASE == LOAD_C)
-			{
-				load_unit<DEPTH, SPLIT>(sU, cv0[c], cv1[c], 0, wu[c]);
-				load_unit<DEPTH, SPLIT>(sV, cv0[c], cv1[c], 0, wv[c]);
-			}
-		}
-		int cbl, cbr;                                  // blocks left / right of the lane's edge
-		if (CBW == 16) { cbl = cbr = yblk; }
-		else { cbl = min(max(cm - 1, 0), last); cbr = min(cm, last); }
-		if (PHASE == LOAD_C)
-		{
-			stream_fetch(a.stream, cur_bit + cbl, sc[0]);
-			if (CBW != 16) stream_fetch(a.stream, cur_bit + cbr, sc[1]);
-			if (has_up)
-			{
-				stream_fetch(a.stream, up_bit + cbl, sc[2]);
-				if (CBW != 16) stream_fetch(a.stream, up_bit + cbr, sc[3]);
-			}
-			return;
-		}
 
-		const uint32_t clo2 = (uint32_t)a.clo * 0x10001u, chi2 = (uint32_t)a.chi * 0x10001u;
-		const uint32_t vcl = stream_cut(sc[0], cur_bit + cbl);
-		const uint32_t vcr = (CBW == 16) ? vcl : stream_cut(sc[1], cur_bit + cbr);
-		const BlockParam ucur0 = block_param<1, CSUBX, CSUBY, L::CRS>(vcl, L::CHROMA_OFF);
-		const BlockParam vcur0 = block_param<2, CSUBX, CSUBY, L::CRS>(vcl, L::CHROMA_OFF);
-		BlockParam ucur1 = ucur0, vcur1 = vcur0;
-		if (CBW != 16)
+	if (PHASE == 0)
+	{
+#pragma unroll
+		for (int g = 0; g < 4; g++)
+			load_unit<DEPTH, SPLIT>(srs, vo0[g], vo1[g], 0, w[g]);
+		// LFSR stream slices of this block row (and the one above): lane l takes dword w0 + l; the
+		// windows of all blocks of the row lie inside the first (nblk + 63) / 32 dwords
+		sw[0] = a.stream[cur_w0 + lane];
+		sw[1] = a.stream[up_w0 + lane];
+		return;
+	}
+
+	// ---- block parameters: windows out of the stream slices (via a per-wave LDS scratch) ------
+	*(uint32_t*)(lds + scratch + 4 * lane) = sw[0];
+	*(uint32_t*)(lds + scratch + 256 + 4 * lane) = sw[1];
+	const int comp = d.plane;
+	const int fsx = comp == 0 ? 0 : (comp == 1 ? 10 : 20);
+	const int fsy = comp == 0 ? 14 : (comp == 1 ? 24 : 4);
+	const int fsb = comp == 0 ? 31 : (comp == 1 ? 2 : 15);
+	const uint32_t bank = luma ? (uint32_t)TableLayoutBase::LUMA_OFF : a.chroma_off;
+	const uint32_t lutp = a.lut_off + (uint32_t)comp * 2048;
+	const uint32_t lo2 = (uint32_t)(luma ? a.ylo : a.clo) * 0x10001u, hi2 = (uint32_t)(luma ? a.yhi : a.chi) * 0x10001u;
+	const int half = 1 << (a.scale_shift - 1);
+	const uint32_t rowoff = (uint32_t)rloc * RS;
+	int wc = 32, wu_ = 0;                                   // vfgs_hw.c:173-188
+	if (has_up) { if (jrow == 0) { wc = SUBY > 1 ? 20 : 12; wu_ = SUBY > 1 ? 20 : 24; } else { wc = 24; wu_ = 12; } }
+
+	auto window = [&](uint32_t slot, uint32_t w0, uint32_t bit) {
+		const uint32_t idx = (bit >> 5) - w0;
+		const uint32_t lo = *(const uint32_t*)(lds + scratch + slot + 4 * idx);
+		const uint32_t hi = *(const uint32_t*)(lds + scratch + slot + 4 * idx + 4);
+		return __builtin_amdgcn_alignbit(hi, lo, bit & 31);
+	};
+
+#pragma unroll
+	for (int g = 0; g < 4; g++)
+	{
+		if (d.tile * 4 + g >= segs)
+			break;                                          // wave-uniform
+		const BlockParam c0 = block_param_rt<SUBX, SUBY, RS>(window(0, cur_w0, cur_bit + bl[g]), bank, fsx, fsy, fsb);
+		const BlockParam c1 = (BW == 16) ? c0 : block_param_rt<SUBX, SUBY, RS>(window(0, cur_w0, cur_bit + br[g]), bank, fsx, fsy, fsb);
+		uint32_t h0, h1;
+		if (BW == 16) { h0 = first[g] ? 0u : 8u * kSlots; h1 = h0 + 4 * kSlots; }
+		else { h0 = 4 * kSlots; h1 = 0; }                   // samples 4..7 of the left block, 0..3 of the right block
+		const uint32_t a0 = c0.addr + rowoff + h0, a1 = c1.addr + rowoff + h1;
+		if (has_up)
 		{
-			ucur1 = block_param<1, CSUBX, CSUBY, L::CRS>(vcr, L::CHROMA_OFF);
-			vcur1 = block_param<2, CSUBX, CSUBY, L::CRS>(vcr, L::CHROMA_OFF);
-		}
-		bool edge_on;
-		uint32_t g0, g1;
-		int relu, relv;
-		if (CBW == 16)
-		{
-			const int jl = c_first ? ju - 1 : ju;
-			edge_on = (lane < a.upt) && (jl >= 0) && (jl + 1 < nunits);
-			g0 = c_first ? 0u : 8u * kSlots;
-			g1 = g0 + 4 * kSlots;
-			relu = __mul24(ucur0.sign, swap_lane_pairs(ucur0.sign));
-			relv = __mul24(vcur0.sign, swap_lane_pairs(vcur0.sign));
+			const BlockParam u0 = block_param_rt<SUBX, SUBY, RS>(window(256, up_w0, up_bit + bl[g]), bank, fsx, fsy, fsb);
+			const BlockParam u1 = (BW == 16) ? u0 : block_param_rt<SUBX, SUBY, RS>(window(256, up_w0, up_bit + br[g]), bank, fsx, fsy, fsb);
+			const uint32_t uoff = (16 / SUBY) * RS + rowoff;
+			grain_unit<DEPTH, true, BW == 16>(lds, w[g], lutp, lutp, a0, a1, __mul24(c0.sign, wc), __mul24(c1.sign, wc),
+			                                  u0.addr + uoff + h0, u1.addr + uoff + h1, __mul24(u0.sign, wu_), __mul24(u1.sign, wu_),
+			                                  edge[g], first[g], 1, 2, 2, a.scale_shift, half, lo2, hi2);
 		}
 		else
 		{
-			edge_on = ((lane & 31) < a.upt / 2) && (cm - 1 >= 0) && (cm <= last);
-			g0 = 4 * kSlots;   // samples 4..7 of the left block
-			g1 = 0;            // samples 0..3 of the right block
-			relu = __mul24(ucur0.sign, ucur1.sign);
-			relv = __mul24(vcur0.sign, vcur1.sign);
+			const int rel = (BW == 16) ? __mul24(c0.sign, swap_lane_pairs(c0.sign)) : __mul24(c0.sign, c1.sign);
+			grain_unit<DEPTH, false, BW == 16>(lds, w[g], lutp + (c0.sign < 0 ? 1024u : 0u), lutp + (c1.sign < 0 ? 1024u : 0u), a0, a1,
+			                                   0, 0, 0, 0, 0, 0, edge[g], first[g], rel, c0.sign < 0 ? 1 : 2, c1.sign < 0 ? 1 : 2,
+			                                   a.scale_shift, half, lo2, hi2);
 		}
-		const uint32_t lutu0 = LUTU + (ucur0.sign < 0 ? 1024u : 0u), lutu1 = LUTU + (ucur1.sign < 0 ? 1024u : 0u);
-		const uint32_t lutv0 = LUTV + (vcur0.sign < 0 ? 1024u : 0u), lutv1 = LUTV + (vcur1.sign < 0 ? 1024u : 0u);
-		const int ru0 = ucur0.sign < 0 ? 1 : 2, ru1 = ucur1.sign < 0 ? 1 : 2;
-		const int rv0 = vcur0.sign < 0 ? 1 : 2, rv1 = vcur1.sign < 0 ? 1 : 2;
-#pragma unroll
-		for (int c = 0; c < CNL; c++)
-		{
-			const uint32_t rowoff = __umul24((uint32_t)crl[c], (uint32_t)L::CRS);
-			const uint32_t ua0 = ucur0.addr + rowoff + g0, ua1 = ucur1.addr + rowoff + g1;
-			const uint32_t va0 = vcur0.addr + rowoff + g0, va1 = vcur1.addr + rowoff + g1;
-			// only accesses whose first row is line j = row * CSUBY <= 1 of the block row can hold overlap lines
-			if (has_up && (CRPL * c * CSUBY <= 1))
-			{
-				const uint32_t wl = stream_cut(sc[2], up_bit + cbl);
-				const uint32_t wr = (CBW == 16) ? wl : stream_cut(sc[3], up_bit + cbr);
-				const BlockParam uup0 = block_param<1, CSUBX, CSUBY, L::CRS>(wl, L::CHROMA_OFF);
-				const BlockParam vup0 = block_param<2, CSUBX, CSUBY, L::CRS>(wl, L::CHROMA_OFF);
-				const BlockParam uup1 = (CBW == 16) ? uup0 : block_param<1, CSUBX, CSUBY, L::CRS>(wr, L::CHROMA_OFF);
-				const BlockParam vup1 = (CBW == 16) ? vup0 : block_param<2, CSUBX, CSUBY, L::CRS>(wr, L::CHROMA_OFF);
-				const int jj = crl[c] * CSUBY;
-				int wc = 32, wu_ = 0;
-				if (jj == 0) { wc = CSUBY > 1 ? 20 : 12; wu_ = CSUBY > 1 ? 20 : 24; }
-				else if (jj == 1) { wc = 24; wu_ = 12; }
-				const uint32_t uoff = (16 / CSUBY) * L::CRS + rowoff;
-				// lanes without overlap must not read past the bank: point their (unused) read at the current row
-				const uint32_t uu0 = wu_ ? uup0.addr + uoff + g0 : ua0, uu1 = wu_ ? uup1.addr + uoff + g1 : ua1;
-				const uint32_t vu0 = wu_ ? vup0.addr + uoff + g0 : va0, vu1 = wu_ ? vup1.addr + uoff + g1 : va1;
-				grain_unit<DEPTH, true, CBW == 16>(lds, wu[c], LUTU, LUTU, ua0, ua1, __mul24(ucur0.sign, wc), __mul24(ucur1.sign, wc),
-				                                   uu0, uu1, __mul24(uup0.sign, wu_), __mul24(uup1.sign, wu_),
-				                                   edge_on, c_first, 1, 2, 2, a.scale_shift, half, clo2, chi2);
-				grain_unit<DEPTH, true, CBW == 16>(lds, wv[c], LUTV, LUTV, va0, va1, __mul24(vcur0.sign, wc), __mul24(vcur1.sign, wc),
-				                                   vu0, vu1, __mul24(vup0.sign, wu_), __mul24(vup1.sign, wu_),
-				                                   edge_on, c_first, 1, 2, 2, a.scale_shift, half, clo2, chi2);
-			}
-			else
-			{
-				grain_unit<DEPTH, false, CBW == 16>(lds, wu[c], lutu0, lutu1, ua0, ua1, 0, 0, 0, 0, 0, 0,
-				                                    edge_on, c_first, relu, ru0, ru1, a.scale_shift, half, clo2, chi2);
-				grain_unit<DEPTH, false, CBW == 16>(lds, wv[c], lutv0, lutv1, va0, va1, 0, 0, 0, 0, 0, 0,
-				                                    edge_on, c_first, relv, rv0, rv1, a.scale_shift, half, clo2, chi2);
-			}
-			if (OUT8)
-			{
-				store_unit_narrow<SPLIT>(dU, dc0[c], dc1[c], wu[c]);
-				store_unit_narrow<SPLIT>(dV, dc0[c], dc1[c], wv[c]);
-			}
-			else
-			{
-				store_unit<DEPTH, SPLIT>(dU, dc0[c], dc1[c], 0, wu[c]);
-				store_unit<DEPTH, SPLIT>(dV, dc0[c], dc1[c], 0, wv[c]);
-			}
-		}
+		if (OUT8) store_unit_narrow<SPLIT>(drs, do0[g], do1[g], w[g]);
+		else      store_unit<DEPTH, SPLIT>(drs, do0[g], do1[g], 0, w[g]);
 	}
 }
 
@@ -600,9 +509,10 @@ template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
 __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4) void grain_kernel(const KernelArgs a)
 {
 	using L = TableLayout<CSUBX, CSUBY>;
-	constexpr int CNL_ = (4 / CSUBY) / ((CSUBX == 1) ? 1 : 2);
+	constexpr int CBW = 16 / CSUBX;
+	constexpr int kScratch = 512;      // per wave: two 256-byte LFSR stream slices
 
-	__shared__ __attribute__((aligned(16))) uint8_t lds[L::BYTES];
+	__shared__ __attribute__((aligned(16))) uint8_t lds[L::BYTES + kWavesPerWG * kScratch];
 
 	// stage banks + LUTs: global (L2 resident) -> LDS, 16 bytes per lane per step
 #if VFGS_ABLATE != 6
@@ -615,60 +525,72 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4)
 	// wave-uniform by construction; telling the compiler keeps item decoding, row offsets and
 	// buffer descriptors in SGPRs (otherwise every buffer instruction gets a waterfall loop)
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t scratch = L::BYTES + wave * kScratch;
 
 	// persistent: the workgroups of one launch share the items round-robin, kWavesPerWG
-	// consecutive items (neighbouring tiles of one line quad) per workgroup and step.
-	// A lane of the first tile of a row has no block to its left; a tile whose last block edge
-	// index exceeds the last block has lanes with no block to their right: those tiles take the
-	// SPLIT form of do_item (wave-uniform test).
-#if VFGS_CHUNKED
-	// each workgroup walks one contiguous run of items (tiles along a row, then the next rows)
-	const int step = kWavesPerWG;
-	const int per_wg = ((a.nitems + (int)gridDim.x - 1) / (int)gridDim.x + kWavesPerWG - 1) / kWavesPerWG * kWavesPerWG;
-	int item = blockIdx.x * per_wg + wave;
-	const int item_end = min(a.nitems, (int)(blockIdx.x + 1) * per_wg);
-#define VFGS_NITEMS item_end
-#else
+	// consecutive items (neighbouring tiles / rows of one plane) per workgroup and step
 	const int step = gridDim.x * kWavesPerWG;
-	int item = blockIdx.x * kWavesPerWG + wave;
-#define VFGS_NITEMS a.nitems
-#endif
-	if (item >= VFGS_NITEMS)
-		return;
-	auto is_split = [&](int it) { const int tx = it % a.ntx; return tx == 0 || (tx + 1) * (a.upt / 2) > a.nblk; };
+	const int per_frame = a.items_y + 2 * a.items_c;
+	auto decode = [&](int item) {
+		ItemDesc d;
+		d.f = item / per_frame;
+		int r = item - d.f * per_frame;
+		if (r < a.items_y) { d.plane = 0; d.row = a.y0 + r / a.tiles_y; d.tile = r % a.tiles_y; }
+		else
+		{
+			r -= a.items_y;
+			d.plane = 1 + (r >= a.items_c);
+			if (r >= a.items_c) r -= a.items_c;
+			d.row = a.crow_first + r / a.tiles_c;
+			d.tile = r % a.tiles_c;
+		}
+		return d;
+	};
+	// a subsampled-chroma lane at the left / right picture edge owns only one valid half: items
+	// that contain such a lane move chroma in two 8-byte halves (wave-uniform)
+	auto run = [&](const ItemDesc d, auto phase, uint32_t (&w)[4][4], uint32_t (&sw)[2]) {
+		constexpr int PH = decltype(phase)::value;
+		if (d.plane == 0)
+			plane_item<DEPTH, 16, 1, 1, L::LRS, OUT8, false, PH>(a, lds, scratch, d, lane, w, sw);
+		else if (CBW == 16 || (d.tile != 0 && d.tile != a.tiles_c - 1))
+			plane_item<DEPTH, CBW, CSUBX, CSUBY, L::CRS, OUT8, false, PH>(a, lds, scratch, d, lane, w, sw);
+		else
+			plane_item<DEPTH, CBW, CSUBX, CSUBY, L::CRS, OUT8, true, PH>(a, lds, scratch, d, lane, w, sw);
+	};
 
-	uint32_t wy[4][4], wu[CNL_][4], wv[CNL_][4];
-	uint32_t sy[2][2], sc[4][2];      // raw LFSR stream dwords of the item's blocks (luma / chroma; current, upper row)
-#define VFGS_PHASE(PH, IT)                                                                                      \
-	do {                                                                                                        \
-		if (is_split(IT)) do_item<DEPTH, CSUBX, CSUBY, OUT8, true, PH>(a, lds, IT, lane, wy, wu, wv, sy, sc);  \
-		else              do_item<DEPTH, CSUBX, CSUBY, OUT8, false, PH>(a, lds, IT, lane, wy, wu, wv, sy, sc); \
-	} while (0)
-
+	const std::integral_constant<int, 0> LOAD;
+	const std::integral_constant<int, 1> COMP;
 #if VFGS_PIPE
-	VFGS_PHASE(LOAD_Y, item);
+	// two register sets: the next item's loads are issued before the current item is computed
+	uint32_t wa[4][4], swa[2], wb[4][4], swb[2];
+	int item = blockIdx.x * kWavesPerWG + wave;
+	if (item >= a.nitems)
+		return;
+	ItemDesc d = decode(item);
+	run(d, LOAD, wa, swa);
 	for (;;)
 	{
-		const int next = item + step;
-		VFGS_PHASE(LOAD_C, item);
-		VFGS_PHASE(COMP_Y, item);
-		if (next < VFGS_NITEMS)
-			VFGS_PHASE(LOAD_Y, next);      // the luma registers are free again: refill them now
-		VFGS_PHASE(COMP_C, item);
-		if (next >= VFGS_NITEMS)
-			break;
-		item = next;
+		int next = item + step;
+		ItemDesc dn = d;
+		if (next < a.nitems) { dn = decode(next); run(dn, LOAD, wb, swb); }
+		run(d, COMP, wa, swa);
+		if (next >= a.nitems) break;
+		item = next; d = dn;
+		next = item + step;
+		if (next < a.nitems) { dn = decode(next); run(dn, LOAD, wa, swa); }
+		run(d, COMP, wb, swb);
+		if (next >= a.nitems) break;
+		item = next; d = dn;
 	}
 #else
-	for (; item < VFGS_NITEMS; item += step)
+	uint32_t w[4][4], sw[2];
+	for (int item = blockIdx.x * kWavesPerWG + wave; item < a.nitems; item += step)
 	{
-		VFGS_PHASE(LOAD_Y, item);
-		VFGS_PHASE(LOAD_C, item);
-		VFGS_PHASE(COMP_Y, item);
-		VFGS_PHASE(COMP_C, item);
+		const ItemDesc d = decode(item);
+		run(d, LOAD, w, sw);
+		run(d, COMP, w, sw);
 	}
 #endif
-#undef VFGS_PHASE
 }
 
 // ---------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ constexpr int kSlots = 8;        // pattern slots per component, vfgs_hw.h:49
 constexpr int kMaxUnits = 64;    // 8-sample units per work item row (one per lane)
 // Tuning knobs (defaults are the shipped configuration; tools/ablate.py overrides them).
 #ifndef VFGS_WAVES
-#define VFGS_WAVES 8
+#define VFGS_WAVES 12
 #endif
 #ifndef VFGS_WG_PER_CU
 #define VFGS_WG_PER_CU 2
@@ -24,7 +24,7 @@ constexpr int kMaxUnits = 64;    // 8-sample units per work item row (one per la
 #define VFGS_CHUNKED 0    // 1: every workgroup gets one contiguous run of items instead of round-robin
 #endif
 #ifndef VFGS_PIPE
-#define VFGS_PIPE 1       // 1: LOAD_C(i), COMP_Y(i), LOAD_Y(i+1), COMP_C(i); 0: load all of item i, then compute it
+#define VFGS_PIPE 0       // 1: issue the next item's loads before computing the current item (two register sets)
 #endif
 #ifndef VFGS_ABLATE
 #define VFGS_ABLATE 0   // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py)
@@ -61,9 +61,8 @@ struct TableLayout {
 	static_assert(BYTES % 16 == 0, "image is copied in 16-byte pieces");
 };
 
-// One launch = nframes x nbr block rows x 4 line quads x ntx tiles work items; one item =
-// `upt` units (<= 512 luma samples) x 4 luma lines of Y plus the co-located Cb/Cr samples,
-// owned by ONE wavefront.
+// One launch = nframes x (Y rows + Cb rows + Cr rows of the stripe) x tiles per row work items;
+// one item = one row of one plane x 4 segments of <= 64 lanes x 8 samples, owned by ONE wavefront.
 struct KernelArgs {
 	const uint8_t* Y;         // source: line `y0` of frame 0 (device)
 	const uint8_t* U;         // source: chroma row y0/csuby of frame 0
@@ -87,10 +86,13 @@ struct KernelArgs {
 	int y0;                   // absolute luma line of the first line of the stripe
 	int nlines;               // luma lines in the stripe
 	int nblk;                 // 16-sample blocks per line = ceil(width/16), vfgs_hw.c:301
-	int ntx;                  // tiles (work items) per line quad
-	int upt;                  // 8-sample units per tile row, even, <= 64
-	int nitems;               // nframes * nbr * 4 * ntx
-	int nbr;                  // block rows touched by the stripe
+	// work items (vfgs_kernel.hip "Work items"): one row of one plane x 4 segments
+	int upt_y, segs_y, tiles_y;   // planes with 16-sample blocks: units per segment (even, <= 64), segments and tiles per row
+	int upt_c, segs_c, tiles_c;   // chroma planes (8-sample blocks: edges per segment; else copies of the *_y values)
+	int crow_first, ncrows;       // chroma rows of the stripe: first absolute row, count
+	int items_y, items_c;         // nlines * tiles_y, ncrows * tiles_c
+	int nitems;                   // nframes * (items_y + 2 * items_c)
+	uint32_t chroma_off, lut_off; // TableLayout offsets of the chroma bank and the LUTs
 	int stride, cstride;      // samples
 	int nframes;
 	int scale_shift;          // vfgs_hw.c:56 (already includes +6-bs)
