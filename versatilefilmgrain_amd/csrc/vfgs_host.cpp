@@ -110,7 +110,8 @@ public:
 	// make the device image cover absolute bits [lo, hi + 64); returns 0 or a HIP error
 	hipError_t ensure(uint64_t lo, uint64_t hi, hipStream_t stream)
 	{
-		const uint64_t wlo = lo >> 5, whi = (hi >> 5) + 4;
+		// + 80: every wave reads a 64-dword slice starting at the dword of its row's first window
+		const uint64_t wlo = lo >> 5, whi = (hi >> 5) + 80;
 		if (cur_ >= 0 && wlo >= slot_[cur_].wbase && whi <= slot_[cur_].wbase + slot_[cur_].nwords)
 			return hipSuccess;
 		const uint32_t reg0 = window(wlo << 5);
@@ -400,6 +401,8 @@ int check_geometry(const State& s, const void* dY, const void* dU, const void* d
 	const unsigned nblk = (width + 15) / 16;
 	if (width <= 128)   // vfgs_hw.c:168
 		return fail(5, "width %u: the hardware layer requires width > 128 (vfgs_hw.c:168)", width);
+	if (nblk > 1984)    // a row's LFSR windows must fit the 64-dword slice a wave keeps in LDS
+		return fail(17, "width %u exceeds the supported 31744 samples", width);
 	if (stride < nblk * 16 || cstride < nblk * 16 / s.csubx)
 		return fail(6, "stride %u/%u too small: whole 16-sample blocks are written (need >= %u/%u)", stride, cstride, nblk * 16, nblk * 16 / s.csubx);
 	if (((uintptr_t)dY | (uintptr_t)dU | (uintptr_t)dV) & 15)
