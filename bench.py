@@ -189,7 +189,7 @@ def main():
                        "pool_frames": pool * frames_per_launch, "msamples_per_s": round(mpix * 1.5, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "grain_kernel<10,2,2>", "launch_us": round(launch_ms * 1e3, 2),
+                         "kernel": "grain_kernel<10,2,2,false>", "launch_us": round(launch_ms * 1e3, 2),
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu:
