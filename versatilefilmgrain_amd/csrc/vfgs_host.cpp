@@ -374,23 +374,26 @@ struct StripePlan {
 // [y, y+n) on stream *positions*; records the registers of line `mark`.
 StripePlan advance_seeds(State& s, unsigned y, unsigned n, unsigned nblk, unsigned mark)
 {
+	// All lines of one block row see the same registers at entry and leave the same registers
+	// behind, so the per-line machine of the reference collapses to one step per block row.
 	StripePlan p{0, 0};
-	for (unsigned yy = y; yy < y + n; yy++)
+	const unsigned end = y + n;
+	for (unsigned a = y; a < end;)
 	{
-		if (yy && (yy & 15) == 0)
+		const unsigned b = std::min(end, (a | 15u) + 1);      // lines [a, b) lie in one block row
+		if (a && (a & 15) == 0)                               // vfgs_hw.c:291-296
 		{
 			s.line_rnd_up = s.line_rnd;
 			s.line_rnd = s.rnd;
 		}
-		s.rnd_up = s.line_rnd_up;
-		s.rnd = s.line_rnd;
-		if (yy == mark)
+		if (mark >= a && mark < b)
 		{
-			p.cur0 = s.rnd;
-			p.up0 = s.rnd_up;
+			p.cur0 = s.line_rnd;                              // vfgs_hw.c:297-298
+			p.up0 = s.line_rnd_up;
 		}
-		s.rnd += nblk;
-		s.rnd_up += nblk;
+		s.rnd = s.line_rnd + nblk;                            // after any line of this block row (vfgs_hw.c:309-310)
+		s.rnd_up = s.line_rnd_up + nblk;
+		a = b;
 	}
 	return p;
 }
