@@ -10,15 +10,15 @@
 // (block_row * blocks_per_line + block), F is the 3-tap filter at block edges, and the
 // window of the block row above feeds the 2-line overlap.
 //
-// Work decomposition (see DESIGN.md "kernel"):
-//   * one WAVEFRONT owns one work item = up to 32 grain blocks (<= 512 luma samples) x 4 luma
-//     lines of Y, plus the co-located Cb/Cr samples; each grain block is served by a fixed
-//     lane pair of that wavefront, which derives the block's LFSR window in registers;
+// Work decomposition (see DESIGN.md "kernel" and "Work items" below):
+//   * one WAVEFRONT owns one work item = one row of one plane x 4 segments (<= 4 KiB
+//     contiguous); each grain block is served by a fixed lane pair of that wavefront, which
+//     derives the block's LFSR window, sign and pattern offsets in registers;
 //   * every lane moves 16 bytes (10-bit) / 8 bytes (8-bit) = 8 samples per access, so one
 //     wave-instruction reads or writes one contiguous <= 1 KiB row segment;
-//   * items are shifted by HALF A BLOCK (8 luma samples) against the block grid, so every
+//   * segments are shifted by HALF A BLOCK (8 samples) against the block grid, so every
 //     block edge -- the only place where a sample depends on its horizontal neighbours --
-//     lies strictly inside an item: no halo, no inter-wave exchange, in-place is race free;
+//     lies strictly inside a segment: no halo, no inter-wave exchange, in-place is race free;
 //   * pattern banks (slot-interleaved) and LUTs are staged once per workgroup in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -20,9 +20,6 @@ constexpr int kMaxUnits = 64;    // 8-sample units per work item row (one per la
 #ifndef VFGS_STAUX
 #define VFGS_STAUX 0      // cache policy bits of the sample stores
 #endif
-#ifndef VFGS_CHUNKED
-#define VFGS_CHUNKED 0    // 1: every workgroup gets one contiguous run of items instead of round-robin
-#endif
 #ifndef VFGS_PIPE
 #define VFGS_PIPE 0       // 1: issue the next item's loads before computing the current item (two register sets)
 #endif
