@@ -398,3 +398,43 @@ def test_line_api_lookahead_sees_late_changes_and_irregular_calls(hip):
             y += 1
         assert a.equal_all(b)
         assert hip.seed_state() == ora.seed_state()
+
+
+def test_fuzz_sizes_formats_and_stripes(hip):
+    """Randomised geometry: widths that give every segment/tile shape (partial last segment, odd
+    number of segments, one- and many-tile rows), heights that are not multiples of 16, uneven
+    host stripes and device stripes with extra row pitch -- against the oracle, whole buffers."""
+    from gpu_util import DevFrame, stream_ptr
+    rng = np.random.default_rng(20260403)
+    names = ["fgs_sei_10_420", "fgs_sei_8_422", "fgs_afgs1_test1_10_444", "fgs_sei_ff_test6_10_444", "fgs_afgs1_test1_8_444",
+             "fgs_sei_ff_test6_8_422", "fgs_sei_ar_test1_8_420", "fgs_sei_10_422"]
+    for it in range(48):
+        name = names[it % len(names)]
+        ora, (depth, sx, sy) = program(hip, name)
+        w = int(rng.choice([int(rng.integers(130, 700)), int(rng.integers(700, 2600)), 1024 + 16 * int(rng.integers(0, 3)), 2040, 129 + int(rng.integers(0, 16))]))
+        h = int(rng.integers(17, 120))
+        if sy == 2:
+            h += h & 1
+        pad = 64 * int(rng.integers(0, 3))
+        f = T.Frame(w, h, depth, sx, sy, stride=((w + 63) // 64 * 64) + pad, cstride=((w // sx + 63) // 64 * 64) + pad)
+        for p in f.planes():
+            p[...] = rng.integers(0, 1 << (10 if depth > 8 else 8), p.shape).astype(f.dtype)
+        want = f.copy()
+        ora.add_grain_frame(want)
+        if it % 2 == 0:      # host stripes of random heights
+            a = f.copy()
+            y = 0
+            while y < h:
+                n = min(h - y, int(rng.integers(1, 40)))
+                hip.add_grain_stripe(a.Y[y].ctypes.data, a.U[y // sy].ctypes.data, a.V[y // sy].ctypes.data, y, w, n, a.stride, a.cstride)
+                y += n
+            got = a
+        else:                # device, 16-aligned parts
+            d = DevFrame(f)
+            cut = 16 * int(rng.integers(0, h // 16 + 1))
+            for (y0, n) in ((0, cut), (cut, h - cut)):
+                if n:
+                    hip.add_grain_stripe_dev(*d.ptrs(y0), y0, w, n, f.stride, f.cstride, stream_ptr())
+            got = d.download()
+        assert got.equal_all(want), (it, name, w, h, pad)
+        assert hip.seed_state() == ora.seed_state()
