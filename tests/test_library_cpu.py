@@ -74,3 +74,14 @@ sys.exit(0 if rc != 0 else 3)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "HAVE_GPU" in r.stdout or "RC" in r.stdout
+
+
+def test_header_is_valid_c_and_links(lib, tmp_path):
+    """gcc -std=c99: the public header as C, every entry point resolved, host-only calls executed."""
+    exe = tmp_path / "c_abi_check"
+    libdir = B.LIB.parent
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{T.ROOT / 'include'}", str(T.ROOT / "tests" / "c_abi_check.c"),
+                    f"-L{libdir}", "-lvfgs_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "27 entry points" in r.stdout and "0x00006072" in r.stdout
