@@ -16,11 +16,34 @@
  *                    itself handles csubx = csuby = 1.  BASELINE config #4
  *                    (2160p 8-bit 4:4:4) needs this.
  *
- * Without either flag it forwards to the reference main() untouched.
+ *   --dump-cfg FILE  append, before every vfgs_init_sei / vfgs_init_afgs1 call, the
+ *                    parameter structure the reference hands to its firmware layer
+ *                    (vfgs_fw.h:51-89) as { u32 kind (0 SEI, 1 AFGS1), u32 nbytes, bytes }.
+ *                    These records are the INPUT fixtures of the device firmware tests
+ *                    (tests/golden/fwcfg/): data, not code.
+ *
+ * Without any of these flags it forwards to the reference main() untouched.
  */
 #define main vfgs_reference_main
 #include "vfgs_main.c"
 #undef main
+
+static const char* dump_name;
+
+static void dump_cfg(void)
+{
+	FILE* f;
+	unsigned kind = afgs1.num_y_points ? 1 : 0;
+	unsigned n = kind ? sizeof(afgs1) : sizeof(sei);
+	if (!dump_name)
+		return;
+	f = fopen(dump_name, "ab");
+	if (!f) { perror(dump_name); exit(2); }
+	fwrite(&kind, 4, 1, f);
+	fwrite(&n, 4, 1, f);
+	fwrite(kind ? (void*)&afgs1 : (void*)&sei, 1, n, f);
+	fclose(f);
+}
 
 static int arg_is(const char* a, const char* s, const char* l)
 {
@@ -39,14 +62,16 @@ int main(int argc, const char** argv)
 	{
 		if (!strcmp(argv[i], "--program-only")) program_only = 1;
 		if (!strcmp(argv[i], "--no-check")) no_check = 1;
+		if (!strcmp(argv[i], "--dump-cfg") && i + 1 < argc) dump_name = argv[i + 1];
 	}
-	if (!program_only && !no_check)
+	if (!program_only && !no_check && !dump_name)
 		return vfgs_reference_main(argc, argv);
 
 	for (int i = 1; i < argc; i++)
 	{
 		const char* a = argv[i];
 		if (!strcmp(a, "--program-only") || !strcmp(a, "--no-check")) continue;
+		else if (!strcmp(a, "--dump-cfg")) { i++; continue; }
 		else if (arg_is(a, "-w", "--width") && i + 1 < argc) width = atoi(argv[++i]);
 		else if (arg_is(a, "-h", "--height") && i + 1 < argc) height = atoi(argv[++i]);
 		else if (arg_is(a, "-b", "--bitdepth") && i + 1 < argc) depth = atoi(argv[++i]);
@@ -68,6 +93,7 @@ int main(int argc, const char** argv)
 	vfgs_set_chroma_subsampling((format < YUV_444) ? 2 : 1, (format < YUV_422) ? 2 : 1);
 	adjust_chroma_cfg();
 	apply_gain(gain);
+	dump_cfg();
 	if (afgs1.num_y_points)
 		vfgs_init_afgs1(&afgs1);
 	else
@@ -98,6 +124,7 @@ int main(int argc, const char** argv)
 			}
 			else if (pop_cfg(gain))
 				break;
+			dump_cfg();
 			if (afgs1.num_y_points)
 				vfgs_init_afgs1(&afgs1);
 			else

@@ -2,6 +2,7 @@
  * include/vfgs_hip.h is valid C and that every declared entry point resolves against
  * libvfgs_hip.so with C linkage -- the way the reference's vfgs_fw.c / vfgs_main.c use it. */
 #include "vfgs_hip.h"
+#include "vfgs_hip_fw.h"
 
 #include <stdio.h>
 
@@ -17,6 +18,8 @@ int main(void)
 		(void (*)(void))vfgs_hip_add_grain_frames_dev, (void (*)(void))vfgs_hip_add_grain_frames_part_dev, (void (*)(void))vfgs_hip_add_grain_copy_dev,
 		(void (*)(void))vfgs_hip_add_grain_copy8_dev, (void (*)(void))vfgs_hip_get_seed_state, (void (*)(void))vfgs_hip_last_error,
 		(void (*)(void))vfgs_hip_last_error_string, (void (*)(void))vfgs_hip_timer_begin, (void (*)(void))vfgs_hip_timer_end, (void (*)(void))vfgs_hip_device_info,
+		/* firmware interface, vfgs_fw.h:91-92, and its extensions */
+		(void (*)(void))vfgs_init_sei, (void (*)(void))vfgs_init_afgs1, (void (*)(void))vfgs_hip_generate_patterns, (void (*)(void))vfgs_hip_get_pattern,
 	};
 	unsigned char lut[256] = {0};
 	signed char pat[64 * 64] = {0};

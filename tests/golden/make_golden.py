@@ -10,6 +10,11 @@ Needs /root/reference and the in-place reference builds of oracle/Makefile
   tests/golden/md5.json                         md5 of the reference CLI's output on the LCG
                                                 synthetic input
   tests/golden/frames/*.npz                     a few complete small reference outputs
+  tests/golden/fwcfg/<cfg>_<depth>_<fmt>.npz    the parameter structures (fgs_sei / fgs_afgs1,
+                                                vfgs_fw.h:51-89) the reference CLI hands to its
+                                                firmware for that command line, in call order:
+                                                the INPUT of the firmware-layer tests, whose
+                                                expected output is the trace of the same name
 
 Nothing here is read at test time from /root/reference; the fixtures are.
 """
@@ -86,7 +91,41 @@ def record_trace(depth, fmt, cfg, dst):
     os.unlink(tname)
 
 
+def record_fwcfg(depth, fmt, cfg, dst):
+    with tempfile.NamedTemporaryFile(suffix=".cfgdump", delete=False) as t:
+        tname = t.name
+    os.unlink(tname)
+    cmd = [str(T.REF_DIR / "vfgs_ref_x"), "--program-only", "--no-check", "--dump-cfg", tname,
+           "-b", str(depth), "-f", fmt, "-r", str(SEED)]
+    if fmt == "420":
+        cmd.remove("--no-check")
+    if cfg:
+        cmd += ["-c", str(CFG / f"{cfg}.cfg")]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    raw = Path(tname).read_bytes()
+    os.unlink(tname)
+    kinds, blobs, off = [], {}, 0
+    while off < len(raw):
+        kind, n = np.frombuffer(raw, dtype=np.uint32, count=2, offset=off)
+        blobs[f"cfg{len(kinds)}"] = np.frombuffer(raw, dtype=np.uint8, count=int(n), offset=off + 8).copy()
+        kinds.append(int(kind))
+        off += 8 + int(n)
+    np.savez_compressed(dst, kinds=np.array(kinds, dtype=np.int32), seed=np.array([SEED], dtype=np.uint32), **blobs)
+
+
+def fwcfg_only():
+    (T.GOLDEN / "fwcfg").mkdir(parents=True, exist_ok=True)
+    cfgs = sorted(p.stem for p in CFG.glob("*.cfg"))
+    jobs = [(c, d, "420") for c in [None] + cfgs for d in (8, 10)] + NON_420
+    for cfg, depth, fmt in jobs:
+        name = f"{cfg or 'default'}_{depth}_{fmt}"
+        record_fwcfg(depth, fmt, cfg, T.GOLDEN / "fwcfg" / f"{name}.npz")
+        print("fwcfg", name, flush=True)
+
+
 def main():
+    if "--fwcfg-only" in sys.argv:
+        return fwcfg_only()
     T.build_oracle()
     (T.GOLDEN / "traces").mkdir(parents=True, exist_ok=True)
     (T.GOLDEN / "frames").mkdir(parents=True, exist_ok=True)
@@ -107,6 +146,8 @@ def main():
         for cfg, depth, fmt in jobs:
             name = f"{cfg or 'default'}_{depth}_{fmt}"
             record_trace(depth, fmt, cfg, T.TRACES / f"{name}.npz")
+            (T.GOLDEN / "fwcfg").mkdir(parents=True, exist_ok=True)
+            record_fwcfg(depth, fmt, cfg, T.GOLDEN / "fwcfg" / f"{name}.npz")
             out = f"{tmp}/out.yuv"
             md5["small"][name] = run_ref(w, h, depth, fmt, cfg, n, inputs[(depth, fmt)], out)
             if name in ("fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_ff_test6_8_422"):

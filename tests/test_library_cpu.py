@@ -22,9 +22,10 @@ def lib():
 
 
 def test_header_symbols_all_exported(lib):
-    header = (T.ROOT / "include" / "vfgs_hip.h").read_text()
+    from versatilefilmgrain_amd import fw
+    header = (T.ROOT / "include" / "vfgs_hip.h").read_text() + (T.ROOT / "include" / "vfgs_hip_fw.h").read_text()
     declared = set(re.findall(r"\b(vfgs_[a-z0-9_]+)\s*\(", header))
-    assert declared == set(hw.EXPORTS), declared ^ set(hw.EXPORTS)
+    assert declared == set(hw.EXPORTS) | set(fw.EXPORTS), declared ^ (set(hw.EXPORTS) | set(fw.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
 
@@ -35,6 +36,29 @@ def test_reference_interface_names_present(lib):
                  "vfgs_set_seed", "vfgs_set_scale_shift", "vfgs_set_depth", "vfgs_set_legal_range",
                  "vfgs_set_chroma_subsampling", "vfgs_add_grain_line"]:
         assert hasattr(lib, name)
+
+
+def test_firmware_interface_names_and_structure_layout(lib):
+    """vfgs_fw.h:51-92: both entry points exported, parameter structures laid out like the
+    reference's (the fixtures are raw dumps of the reference's own structures)."""
+    import ctypes
+    from versatilefilmgrain_amd import fw
+    assert hasattr(lib, "vfgs_init_sei") and hasattr(lib, "vfgs_init_afgs1")
+    sizes = {0: ctypes.sizeof(fw.FgsSei), 1: ctypes.sizeof(fw.FgsAfgs1)}
+    for name in ("fgs_sei_10_420", "fgs_afgs1_test1_10_420"):
+        seed, cfgs = T.load_fwcfg(name)
+        assert seed == 12345
+        for kind, raw in cfgs:
+            assert len(raw) == sizes[kind]
+            fw.struct_from_bytes(kind, raw)
+    # the default SEI of the reference CLI (vfgs_main.c:69-110), as dumped: 8 luma intervals, scale 100.. , cut-offs 7..14
+    _, cfgs = T.load_fwcfg("default_10_420")
+    sei = fw.struct_from_bytes(*cfgs[0])
+    assert sei.model_id == 0 and sei.log2_scale_factor == 5 and list(sei.num_intensity_intervals) == [8, 8, 8]
+    assert [sei.comp_model_value[0][k][1] for k in range(8)] == [7, 8, 9, 10, 11, 12, 13, 14]
+    _, cfgs = T.load_fwcfg("fgs_afgs1_test1_10_420")
+    a = fw.struct_from_bytes(*cfgs[1])
+    assert a.num_y_points >= 1 and 1 <= a.ar_coeff_lag <= 3 and 6 <= a.ar_coeff_shift <= 9
 
 
 def test_seed_registers_after_set_seed_match_oracle(lib):
@@ -84,4 +108,4 @@ def test_header_is_valid_c_and_links(lib, tmp_path):
                     f"-L{libdir}", "-lvfgs_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "27 entry points" in r.stdout and "0x00006072" in r.stdout
+    assert "31 entry points" in r.stdout and "0x00006072" in r.stdout

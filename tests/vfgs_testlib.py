@@ -293,3 +293,42 @@ class ReferenceHW:
             if (y & 1) or f.suby == 1:
                 pu += f.cstride * sz
                 pv += f.cstride * sz
+
+
+# --------------------------------------------------------------------------- firmware fixtures
+
+FWCFG = GOLDEN / "fwcfg"
+
+
+def load_fwcfg(name: str):
+    """-> (seed, [(kind, struct bytes), ...]) the reference CLI handed to its firmware, in call order."""
+    with np.load(FWCFG / f"{name}.npz") as z:
+        kinds = [int(k) for k in z["kinds"]]
+        return int(z["seed"][0]), [(k, z[f"cfg{i}"].tobytes()) for i, k in enumerate(kinds)]
+
+
+class BankModel:
+    """What the setters leave in the pattern banks (vfgs_hw.c:314-325), for comparing a trace with
+    the banks of an implementation.  Only the region the hardware layer reads is kept."""
+
+    def __init__(self):
+        self.subx = self.suby = 2
+        self.luma, self.chroma = {}, {}
+
+    def set_luma_pattern(self, i, P):
+        self.luma[i] = np.frombuffer(bytes(P), dtype=np.int8)[:4096].reshape(64, 64).copy()
+
+    def set_chroma_pattern(self, i, P):
+        p = np.frombuffer(bytes(P), dtype=np.int8)
+        rows, cols, pitch = 64 // self.suby, 64 // self.subx, 64 // self.suby
+        self.chroma[i] = np.stack([p[pitch * r: pitch * r + cols] for r in range(rows)]).copy()
+
+    def set_chroma_subsampling(self, x, y):
+        self.subx, self.suby = x, y
+
+    def set_scale_lut(self, c, lut): pass
+    def set_pattern_lut(self, c, lut): pass
+    def set_seed(self, s): pass
+    def set_scale_shift(self, s): pass
+    def set_depth(self, d): pass
+    def set_legal_range(self, l): pass

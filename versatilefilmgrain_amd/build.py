@@ -14,8 +14,10 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libvfgs_hip.so"
-SOURCES = [CSRC / "vfgs_kernel.hip", CSRC / "vfgs_host.cpp"]
-HEADERS = [CSRC / "vfgs_layout.h", PKG.parent / "include" / "vfgs_hip.h"]
+SOURCES = [CSRC / "vfgs_kernel.hip", CSRC / "vfgs_fw_kernel.hip", CSRC / "vfgs_host.cpp", CSRC / "vfgs_fw_host.cpp"]
+FW_TABLES = CSRC / "fw_tables.bin"   # model constants, linked into the library as data (oracle/dump_fw_tables.c)
+HEADERS = [CSRC / "vfgs_layout.h", CSRC / "vfgs_fw_layout.h", FW_TABLES,
+           PKG.parent / "include" / "vfgs_hip.h", PKG.parent / "include" / "vfgs_hip_fw.h"]
 ARCH = "gfx950"
 
 
@@ -39,7 +41,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     with tempfile.TemporaryDirectory(prefix="vfgs_build_") as tmp:
         out = Path(tmp) / LIB.name
         cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-o", str(out)] + [str(s) for s in SOURCES]
+               "-Wall", "-Wno-unused-function", f'-DVFGS_FW_TABLES_PATH="{FW_TABLES}"',
+               "-o", str(out)] + [str(s) for s in SOURCES]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)

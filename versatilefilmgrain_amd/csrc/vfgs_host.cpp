@@ -18,12 +18,24 @@
 #include <vector>
 
 #include "../../include/vfgs_hip.h"
+#include "../../include/vfgs_hip_fw.h"
+#include "vfgs_fw_layout.h"
 #include "vfgs_layout.h"
 
 namespace vfgs {
 hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, int grid, hipStream_t stream);
 int table_bytes(int csubx, int csuby);
+hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
+hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby, hipStream_t stream);
 }
+
+// The constant tables of the grain models (oracle/dump_fw_tables.c documents origin and layout),
+// linked in as data.
+#if !defined(__HIP_DEVICE_COMPILE__)
+__asm__(".section .rodata\n.balign 16\n.hidden vfgs_fw_blob\n.globl vfgs_fw_blob\nvfgs_fw_blob:\n.incbin \"" VFGS_FW_TABLES_PATH "\"\n"
+        ".hidden vfgs_fw_blob_end\n.globl vfgs_fw_blob_end\nvfgs_fw_blob_end:\n.previous\n");
+#endif
+extern "C" const unsigned char vfgs_fw_blob[], vfgs_fw_blob_end[];
 
 namespace {
 
@@ -242,6 +254,16 @@ struct State {
 	hipStream_t own_stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
+	// firmware layer on the device (include/vfgs_hip_fw.h): slots whose pattern was generated on
+	// the device live in dev_bank; the host mirror above holds the slots set through the setters
+	uint32_t dev_origin[2] = {0, 0};          // bit k: slot k of bank c is device-generated
+	int8_t* dev_bank = nullptr;               // [2][kSlots][64][64]
+	int8_t* dev_raw = nullptr;                // [kSlots][32*32]
+	vfgs::FwConstants* fw_const = nullptr;    // device copy of the model constants + noise streams
+	hipEvent_t fw_ev = nullptr;               // after the last generation (own_stream)
+	hipEvent_t patch_ev = nullptr;            // after the last kernel that read dev_bank
+	bool patch_seen = false;
+
 	// ---- look-ahead of the line API (see line_call()) -----------------------------------
 	uint64_t gen = 0;                 // bumped by every call that changes state other than a line call
 	struct LineAhead {
@@ -356,7 +378,79 @@ int upload_tables(State& s, hipStream_t stream)
 	else if (s.csubx == 1 && s.csuby == 1) build_tables<1, 1>(s, img);
 	else build_tables<1, 2>(s, img);
 	HIP_TRY(hipMemcpyAsync(dst, img.data(), bytes, hipMemcpyHostToDevice, stream));
+	if (s.dev_origin[0] | s.dev_origin[1])
+	{
+		// device-generated slots never visit the host: copy them bank -> image on the device
+		HIP_TRY(hipStreamWaitEvent(stream, s.fw_ev, 0));
+		HIP_TRY(vfgs::launch_fw_patch((uint8_t*)dst, s.dev_bank, s.dev_origin[0], s.dev_origin[1], s.csubx, s.csuby, stream));
+		HIP_TRY(hipEventRecord(s.patch_ev, stream));
+		s.patch_seen = true;
+	}
 	s.tables_dirty = false;
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// pattern generation on the device
+
+int fw_prepare(State& s)
+{
+	if (s.fw_const) return 0;
+	if ((size_t)(vfgs_fw_blob_end - vfgs_fw_blob) != 7168)
+		return fail(30, "embedded model tables have the wrong size");
+	std::vector<uint8_t> img(sizeof(vfgs::FwConstants));
+	memcpy(img.data(), vfgs_fw_blob, 7168);
+	vfgs::FwConstants* k = (vfgs::FwConstants*)img.data();
+	for (int i = 0; i < vfgs::kFwSeeds; i++)
+	{
+		// the firmware's generator (vfgs_fw.c:284-295) is the hardware layer's LFSR: stream word w
+		// is the register after 32*w steps, from word 32 on W[n] = W[n-31] ^ W[n-3]
+		uint32_t reg = k->seed[i];
+		for (int w = 0; w < vfgs::kFwStreamWords; w++)
+		{
+			if (w < 32) { k->stream[i][w] = reg; for (int b = 0; b < 32; b++) reg = lfsr_step(reg); }
+			else k->stream[i][w] = k->stream[i][w - 31] ^ k->stream[i][w - 3];
+		}
+	}
+	HIP_TRY(hipMalloc((void**)&s.fw_const, sizeof(vfgs::FwConstants)));
+	HIP_TRY(hipMemcpy(s.fw_const, img.data(), img.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&s.dev_bank, 2 * vfgs::kSlots * 4096));
+	HIP_TRY(hipMemset(s.dev_bank, 0, 2 * vfgs::kSlots * 4096));
+	HIP_TRY(hipMalloc((void**)&s.dev_raw, vfgs::kSlots * 1024));
+	HIP_TRY(hipEventCreateWithFlags(&s.fw_ev, hipEventDisableTiming));
+	HIP_TRY(hipEventCreateWithFlags(&s.patch_ev, hipEventDisableTiming));
+	return 0;
+}
+
+int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
+{
+	State& s = S();
+	if (n <= 0) return 0;
+	if (n > vfgs::kFwMaxJobs) return fail(31, "vfgs_hip_generate_patterns: %d jobs (at most %d)", n, vfgs::kFwMaxJobs);
+	vfgs::FwLaunch L{};
+	L.last_luma = -1;
+	bool seen_chroma = false;
+	for (int i = 0; i < n; i++)
+	{
+		const vfgs_hip_pattern_job& j = jobs[i];
+		if (j.index < 0 || j.index >= vfgs::kSlots) return fail(20, "pattern job %d: slot %d", i, j.index);
+		if (j.seed_index < 0 || j.seed_index >= vfgs::kFwSeeds) return fail(32, "pattern job %d: seed index %d", i, j.seed_index);
+		if (j.kind == 0) { if (j.fh > 32767 || j.fv > 32767 || j.fh < -32768 || j.fv < -32768) return fail(33, "pattern job %d: cut-off out of int16 range", i); }
+		else if (j.kind == 1) { if (j.scale < 1 || j.scale > 15 || j.shift < 1 || j.shift > 7) return fail(34, "pattern job %d: scale %d / shift %d", i, j.scale, j.shift); }
+		else return fail(35, "pattern job %d: kind %d", i, j.kind);
+		if (j.chroma) seen_chroma = true;
+		else { if (seen_chroma) return fail(36, "pattern jobs: luma jobs must come first"); L.last_luma = j.index; }
+		L.job[i] = j;
+	}
+	if (int e = ensure_init(-1)) return e;
+	if (int e = fw_prepare(s)) return e;
+	L.k = s.fw_const; L.bank = s.dev_bank; L.chroma_raw = s.dev_raw;
+	L.njobs = n; L.csubx = s.csubx; L.csuby = s.csuby;
+	if (s.patch_seen) HIP_TRY(hipStreamWaitEvent(s.own_stream, s.patch_ev, 0));   // earlier images may still be assembling
+	HIP_TRY(vfgs::launch_fw_generate(L, s.own_stream));
+	HIP_TRY(hipEventRecord(s.fw_ev, s.own_stream));
+	for (int i = 0; i < n; i++) s.dev_origin[jobs[i].chroma ? 1 : 0] |= 1u << jobs[i].index;
+	s.tables_dirty = true;
 	return 0;
 }
 
@@ -745,6 +839,7 @@ void vfgs_set_luma_pattern(int index, signed char* P)
 	S().gen++;
 	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_luma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:316)"); }
 	memcpy(S().bank[0][index], P, 64 * 64);   // vfgs_hw.c:317
+	S().dev_origin[0] &= ~(1u << index);
 	S().tables_dirty = true;
 }
 
@@ -756,6 +851,7 @@ void vfgs_set_chroma_pattern(int index, signed char* P)
 	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_chroma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:322)"); }
 	for (int i = 0; i < 64 / s.csuby; i++)   // vfgs_hw.c:323-324: pitch from csuby, length from csubx
 		memcpy(s.bank[1][index][i], P + (64 / s.csuby) * i, 64 / s.csubx);
+	s.dev_origin[1] &= ~(1u << index);
 	s.tables_dirty = true;
 }
 
@@ -847,6 +943,7 @@ void vfgs_hip_reset_state(void)
 	memset(s.bank, 0, sizeof s.bank);
 	memset(s.slut, 0, sizeof s.slut);
 	memset(s.plut, 0, sizeof s.plut);
+	s.dev_origin[0] = s.dev_origin[1] = 0;
 	s.scale_shift = 5 + 6;
 	s.bs = 0;
 	s.ymin = s.cmin = 0;
@@ -869,6 +966,11 @@ void vfgs_hip_shutdown(void)
 	State& s = S();
 	if (!s.inited) return;
 	(void)hipDeviceSynchronize();
+	// device-generated patterns move to the host mirror so the programmed state survives
+	for (int c = 0; c < 2; c++)
+		for (int k = 0; k < vfgs::kSlots; k++)
+			if (s.dev_origin[c] >> k & 1)
+				(void)hipMemcpy(s.bank[c][k], s.dev_bank + (size_t)(c * vfgs::kSlots + k) * 4096, 4096, hipMemcpyDeviceToHost);
 	s.tables_ring.release();
 	s.lfsr.release();
 	for (int i = 0; i < 3; i++) { if (s.stage[i]) (void)hipFree(s.stage[i]); s.stage[i] = nullptr; s.stage_cap[i] = 0; }
@@ -879,6 +981,14 @@ void vfgs_hip_shutdown(void)
 		s.la.in[i] = s.la.out[i] = nullptr; s.la.cap[i] = 0;
 	}
 	s.la.valid = false;
+	if (s.fw_const) (void)hipFree(s.fw_const);
+	if (s.dev_bank) (void)hipFree(s.dev_bank);
+	if (s.dev_raw) (void)hipFree(s.dev_raw);
+	if (s.fw_ev) (void)hipEventDestroy(s.fw_ev);
+	if (s.patch_ev) (void)hipEventDestroy(s.patch_ev);
+	s.fw_const = nullptr; s.dev_bank = nullptr; s.dev_raw = nullptr; s.fw_ev = s.patch_ev = nullptr;
+	s.patch_seen = false;
+	s.dev_origin[0] = s.dev_origin[1] = 0;
 	if (s.own_stream) (void)hipStreamDestroy(s.own_stream);
 	if (s.ev0) (void)hipEventDestroy(s.ev0);
 	if (s.ev1) (void)hipEventDestroy(s.ev1);
@@ -979,6 +1089,28 @@ void vfgs_hip_get_seed_state(uint32_t out[4])
 	out[1] = s.lfsr.window(s.rnd_up);
 	out[2] = s.lfsr.window(s.line_rnd);
 	out[3] = s.lfsr.window(s.line_rnd_up);
+}
+
+int vfgs_hip_generate_patterns(const vfgs_hip_pattern_job* jobs, int n)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	return fw_generate(jobs, n);
+}
+
+int vfgs_hip_get_pattern(int chroma, int index, signed char out[64 * 64])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	if (chroma < 0 || chroma > 1 || index < 0 || index >= vfgs::kSlots) return fail(20, "vfgs_hip_get_pattern: bank %d slot %d", chroma, index);
+	if (s.dev_origin[chroma] >> index & 1)
+	{
+		HIP_TRY(hipStreamSynchronize(s.own_stream));
+		HIP_TRY(hipMemcpy(out, s.dev_bank + (size_t)(chroma * vfgs::kSlots + index) * 4096, 4096, hipMemcpyDeviceToHost));
+	}
+	else
+		memcpy(out, s.bank[chroma][index], 4096);
+	return 0;
 }
 
 int vfgs_hip_last_error(void) { return g_err; }
