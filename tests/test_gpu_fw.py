@@ -210,3 +210,61 @@ def test_random_parameter_sets_vs_real_reference_firmware(hip, seed):
     host_frame_call(hip, a)
     ref.add_grain_frame(b)
     assert a.equal_all(b)
+
+
+def test_reference_cli_with_our_firmware_and_hardware_layer(hip, tmp_path):
+    """DROP-IN at the firmware interface: only the reference's vfgs_main.c + yuv.c (compiled
+    unmodified, oracle/_ref/vfgs_hip_cli_fw); vfgs_init_sei / vfgs_init_afgs1 and the hardware
+    layer come from libvfgs_hip.so.  Must write the same file as the all-reference binary,
+    including configuration switches at frames 1 and 2 (`-c <poc>:file`, vfgs_main.c:773-781).
+    The cfg files are written here (the reference's corpus does not travel)."""
+    import subprocess
+    cli, ref = T.REF_DIR / "vfgs_hip_cli_fw", T.REF_DIR / "vfgs_ref"
+    if not (cli.exists() and ref.exists()):
+        pytest.skip("oracle/_ref binaries were not prebuilt")
+    ff = tmp_path / "ff.cfg"
+    ff.write_text("\n".join([
+        "SEIFGCModelID : 0", "SEIFGCLog2ScaleFactor : 4",
+        "SEIFGCCompModelPresentComp0 : 1", "SEIFGCCompModelPresentComp1 : 1", "SEIFGCCompModelPresentComp2 : 1",
+        "SEIFGCNumIntensityIntervalMinus1Comp0 : 2", "SEIFGCNumIntensityIntervalMinus1Comp1 : 0",
+        "SEIFGCNumIntensityIntervalMinus1Comp2 : 1",
+        "SEIFGCNumModelValuesMinus1Comp0 : 2", "SEIFGCNumModelValuesMinus1Comp1 : 2", "SEIFGCNumModelValuesMinus1Comp2 : 2",
+        "SEIFGCIntensityIntervalLowerBoundComp0 : 0 70 150", "SEIFGCIntensityIntervalUpperBoundComp0 : 69 149 255",
+        "SEIFGCIntensityIntervalLowerBoundComp1 : 0", "SEIFGCIntensityIntervalUpperBoundComp1 : 255",
+        "SEIFGCIntensityIntervalLowerBoundComp2 : 0 128", "SEIFGCIntensityIntervalUpperBoundComp2 : 127 255",
+        "SEIFGCCompModelValuesComp0 : 90 6 9 120 10 10 60 13 4",
+        "SEIFGCCompModelValuesComp1 : 70 5 5", "SEIFGCCompModelValuesComp2 : 40 4 6 80 7 3", ""]))
+    ar = tmp_path / "ar.cfg"
+    ar.write_text("\n".join([
+        "SEIFGCModelID : 1", "SEIFGCLog2ScaleFactor : 5",
+        "SEIFGCCompModelPresentComp0 : 1", "SEIFGCCompModelPresentComp1 : 0", "SEIFGCCompModelPresentComp2 : 0",
+        "SEIFGCNumIntensityIntervalMinus1Comp0 : 1", "SEIFGCNumModelValuesMinus1Comp0 : 5",
+        "SEIFGCIntensityIntervalLowerBoundComp0 : 0 100", "SEIFGCIntensityIntervalUpperBoundComp0 : 99 255",
+        "SEIFGCCompModelValuesComp0 : 80 40 0 -12 20 9 120 -30 0 14 25 -6", ""]))
+    av = tmp_path / "afgs1.cfg"
+    av.write_text("\n".join([
+        "AFGS1GrainSeed : 4711", "AFGS1NumYPoints : 3", "AFGS1PointYValues : 0 120 255", "AFGS1PointYScaling : 30 90 50",
+        "AFGS1ChromaScalingFromLuma : 0", "AFGS1NumCbPoints : 2", "AFGS1PointCbValues : 10 240", "AFGS1PointCbScaling : 60 20",
+        "AFGS1NumCrPoints : 2", "AFGS1PointCrValues : 0 255", "AFGS1PointCrScaling : 25 70",
+        "AFGS1GrainScaling : 10", "AFGS1ARCoeffLag : 2",
+        "AFGS1ARCoeffsY : 3 -5 8 -2 1 6 -20 30 -9 4 12 -40",
+        "AFGS1ARCoeffsCb : -2 4 -7 3 0 5 18 -25 7 -3 10 35 0",
+        "AFGS1ARCoeffsCr : 1 -3 6 -4 2 -6 15 22 -8 5 -11 30 0",
+        "AFGS1ARCoeffShift : 7", "AFGS1GrainScaleShift : 1", "AFGS1OverlapFlag : 1", "AFGS1ClipToRestrictedRange : 1", ""]))
+    w, h, n = 208, 160, 4
+    for depth in (10, 8):
+        frames, _ = T.lcg_frames(w, h, depth, 2, 2, n)
+        inp = tmp_path / f"in{depth}.yuv"
+        inp.write_bytes(b"".join(f.picture_bytes() for f in frames))
+        for cfgs in ([str(ff)], [str(ar)], [str(av)], [str(ff), f"1:{av}", f"2:{ar}", f"3:{ff}"]):
+            outs = []
+            for exe in (ref, cli):
+                out = tmp_path / f"{exe.name}_{depth}.yuv"
+                cmd = [str(exe), "-w", str(w), "-h", str(h), "-b", str(depth), "-n", str(n), "-r", "777"]
+                for c in cfgs:
+                    cmd += ["-c", c]
+                subprocess.run(cmd + [str(inp), str(out)], check=True, stdout=subprocess.DEVNULL, timeout=600)
+                outs.append(out.read_bytes())
+            assert len(outs[0]) == len(inp.read_bytes())
+            assert outs[0] != inp.read_bytes()          # grain was really added
+            assert outs[0] == outs[1], cfgs

@@ -5,14 +5,14 @@
 //   frequency-filtered patterns (SEI model 0)         vfgs_fw.c:297-408
 //       band-limited Gaussian noise in the low-frequency corner of an NxN block (N = 64 luma,
 //       32 chroma), two integer matrix passes with the H.266 DCT-II basis, clip to +-127.
-//       -> fw_ff_kernel: one 256-thread workgroup per pattern, block/basis/intermediate in LDS.
+//       -> fw_ff_kernel: one 1024-thread workgroup per pattern, block/basis/intermediate in LDS.
 //   auto-regressive patterns (SEI model 1, AFGS1)      vfgs_fw.c:410-502
 //       a causal 4x7 filter run in raster order over 82x73 (luma) or 44x38 (chroma) samples,
 //       Gaussian noise added to every sample, a 64x64 / 32x32 window cropped out.
 //       Sequential on the CPU; sample (y,x) needs row y up to x-1 and rows y-1..y-3 up to
-//       x+3, so rows can run skewed by 4 columns: step t handles x = t - 4y of every row.
-//       -> fw_ar_kernel: one wavefront per pattern, lane l owns row (t>>2) - l, <= 21 lanes
-//          busy, 82 + 4*72 = 370 steps instead of 5986.
+//       x+L, so rows can run skewed by L+1 columns: step t handles x = t - (L+1)y of every row.
+//       -> fw_ar_kernel: one wavefront per pattern, lane = row, windows in registers, the row
+//          above handed over by DPP; 82 + 4*72 = 370 steps (L = 3) instead of 5986.
 //
 // Both draw their noise from the firmware's generator, which is the hardware layer's LFSR
 // (vfgs_fw.c:284-295): the value used at step n is the 11-bit window at bit n of a per-seed
@@ -50,7 +50,7 @@ __device__ inline void put_sample(const FwLaunch& L, const vfgs_hip_pattern_job&
 
 // ---------------------------------------------------------------------------------------
 // frequency-filtered pattern: vfgs_fw.c:362-408 (fill) + :297-360 (two basis passes)
-__global__ __launch_bounds__(256) void fw_ff_kernel(FwLaunch L)
+__global__ __launch_bounds__(1024) void fw_ff_kernel(FwLaunch L)
 {
 	const vfgs_hip_pattern_job& jb = L.job[blockIdx.x];
 	if (jb.kind != 0) return;
@@ -66,94 +66,197 @@ __global__ __launch_bounds__(256) void fw_ff_kernel(FwLaunch L)
 	const int fh = min(gw * (jb.fh + 1), N); // vfgs_fw.c:366-367, :389-390
 	const int fv = min(gw * (jb.fv + 1), N);
 
-	for (int i = tid; i < 1024; i += 256) ((uint32_t*)D)[i] = ((const uint32_t*)L.k->dct)[i];
-	for (int i = tid; i < 512; i += 256) ((uint32_t*)G)[i] = ((const uint32_t*)L.k->gauss)[i];
+	((uint32_t*)D)[tid] = ((const uint32_t*)L.k->dct)[tid];
+	if (tid < 512) ((uint32_t*)G)[tid] = ((const uint32_t*)L.k->gauss)[tid];
 	if (tid < 40) W[tid] = L.k->stream[jb.seed_index][tid];
 	__syncthreads();
 
 	// noise in the low-frequency corner, zero elsewhere; one generator step per group of gw samples
-	for (int g = tid; g < N * 16; g += 256)
+	if (tid < N * 16)
 	{
-		const int l = g >> 4, k = (g & 15) * gw;
-		const int r = noise_index(W, g);
+		const int l = tid >> 4, k = (tid & 15) * gw;
+		const int r = noise_index(W, tid);
 		const bool in = k < fh && l < fv;
 		for (int j = 0; j < gw; j++)
-			B[l * N + k + j] = in ? G[(r + j) & 2047] : (int8_t)0;
+			B[l * N + k + j] = (in && (tid || j)) ? G[(r + j) & 2047] : (int8_t)0;   // (tid || j): no DC (vfgs_fw.c:383, :406)
 	}
-	__syncthreads();
-	if (tid == 0) B[0] = 0;                  // no DC (vfgs_fw.c:383, :406)
 	__syncthreads();
 
+	// Each thread owns column i and rows j0, j0 + step, ... (4 outputs for N = 64, 1 for N = 32),
+	// so one read of B / X serves all of them.
+	const int i = tid % N, j0 = tid / N, jstep = 1024 / N, per = N * N / 1024;
+	int acc[4];
 	// vertical pass; rows >= fv of B are zero and are skipped
-	for (int o = tid; o < N * N; o += 256)
+	for (int m = 0; m < 4; m++) acc[m] = N == 64 ? 256 : 128;   // vfgs_fw.c:307, :340
+	for (int k = 0; k < fv; k++)
 	{
-		const int j = o / N, i = o % N;
-		int acc = N == 64 ? 256 : 128;       // vfgs_fw.c:307, :340
-		for (int k = 0; k < fv; k++)
-			acc += (int)D[k * dstep * 64 + j] * (int)B[k * N + i];
-		X[o] = (int16_t)(acc >> (N == 64 ? 9 : 8));
+		const int b = B[k * N + i];
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+			if (m < per) acc[m] = __mul24((int)D[k * dstep * 64 + j0 + m * jstep], b) + acc[m];
 	}
+	for (int m = 0; m < per; m++) X[(j0 + m * jstep) * N + i] = (int16_t)(acc[m] >> (N == 64 ? 9 : 8));
 	__syncthreads();
 	// horizontal pass + clip; columns >= fh of X are zero
-	for (int o = tid; o < N * N; o += 256)
+	for (int m = 0; m < 4; m++) acc[m] = 256;                   // vfgs_fw.c:318, :351
+	for (int k = 0; k < fh; k++)
 	{
-		const int j = o / N, i = o % N;
-		int acc = 256;                       // vfgs_fw.c:318, :351
-		for (int k = 0; k < fh; k++)
-			acc += (int)X[j * N + k] * (int)D[k * dstep * 64 + i];
-		put_sample(L, jb, j, i, clip127(acc >> 9));
+		const int d = D[k * dstep * 64 + i];
+#pragma unroll
+		for (int m = 0; m < 4; m++)
+			if (m < per) acc[m] = __mul24((int)X[(j0 + m * jstep) * N + k], d) + acc[m];
 	}
+	for (int m = 0; m < per; m++) put_sample(L, jb, j0 + m * jstep, i, clip127(acc[m] >> 9));
 }
 
 // ---------------------------------------------------------------------------------------
-// auto-regressive pattern: vfgs_fw.c:464-501, rows skewed by four columns
-__global__ __launch_bounds__(64) void fw_ar_kernel(FwLaunch L)
+// auto-regressive pattern: vfgs_fw.c:464-501
+//
+// One wavefront per pattern, lane = row (rows 64..72 of the luma buffer are a second turn of
+// lanes 0..8).  With taps reaching L columns to the right in the rows above, row y can run
+// K = L+1 columns behind row y-1: at step t lane l works on column t - K*l.  Everything a
+// sample needs is then already in registers or long since in LDS:
+//   * the row above: the value lane l-1 produced in the previous step is exactly the new right
+//     edge (column x+L) of this lane's window -- passed with a wave_ror DPP move, no LDS;
+//   * rows y-2, y-3: their column x+L was written at least K steps ago; loaded one step ahead;
+//   * the row itself: the lane's own last L results;
+//   * the noise term: pre-computed for all samples by all 64 lanes into the buffer itself, the
+//     sample later overwrites its own noise.
+// The windows are kept in registers and rotate through an unrolled loop of 2L+1 steps, so the
+// loop has no barrier, no dependent LDS round trip, and no window copies.
+__device__ inline int wave_ror1(int v)
+{
+	return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+}
+
+template <int L>
+__device__ __forceinline__ void ar_rows(int8_t* buf, const short* coef, int width, int height, int scale, int lane)
+{
+	constexpr int K = L + 1, WN = 2 * L + 1;
+	int ca[L][WN], co[L];
+#pragma unroll
+	for (int r = 0; r < L; r++)
+#pragma unroll
+		for (int p = 0; p < WN; p++)
+			ca[r][p] = coef[(3 - (r + 1)) * 7 + 3 + (p - L)];     // row y-(r+1), column x+(p-L)
+#pragma unroll
+	for (int i = 0; i < L; i++)
+		co[i] = coef[3 * 7 + 3 - (i + 1)];                         // row y, column x-(i+1)
+
+	int win[L][WN], own[L];
+#pragma unroll
+	for (int r = 0; r < L; r++)
+#pragma unroll
+		for (int p = 0; p < WN; p++) win[r][p] = 0;
+#pragma unroll
+	for (int i = 0; i < L; i++) own[i] = 0;
+
+	const int rnd = 1 << (scale - 1);
+	const int second_at = 64 * K - L;          // lanes 0.. start feeding their second row (y = lane + 64) here
+	const int steps = width + K * (height - 1);
+	auto coords = [&](int t, int& y, int& x) {
+		const int u = t - K * lane;
+		const bool second = u >= second_at;
+		x = second ? u - 64 * K : u;
+		y = second ? lane + 64 : lane;
+	};
+	// operands that are actually used lie inside the buffer; everything else may read any cell
+	const int last = width * height - 1;
+	auto at = [&](int y, int x) { return min(max(y * width + x, 0), last); };
+
+	int y, x;
+	coords(0, y, x);
+	int nz = buf[at(y, x)];
+	int pre[L];
+#pragma unroll
+	for (int r = 1; r < L; r++) pre[r] = buf[at(y - r - 1, x + L)];
+	int out = 0;
+
+	for (int t0 = 0; t0 < steps; t0 += WN)
+	{
+#pragma unroll
+		for (int s = 0; s < WN; s++)
+		{
+			const int t = t0 + s;
+			coords(t, y, x);
+			// new right edge of every window (logical position WN-1 lives at physical (WN-1+s) % WN)
+			win[0][(WN - 1 + s) % WN] = wave_ror1(out);
+#pragma unroll
+			for (int r = 1; r < L; r++) win[r][(WN - 1 + s) % WN] = pre[r];
+			// int8 samples x int16 taps: 24-bit multiplies; one accumulator per row keeps the chains short
+			int acc[L + 1];
+#pragma unroll
+			for (int r = 0; r < L; r++)
+			{
+				acc[r] = 0;
+#pragma unroll
+				for (int p = 0; p < WN; p++)
+					acc[r] = __mul24(ca[r][p], win[r][(p + s) % WN]) + acc[r];
+			}
+			acc[L] = 0;
+#pragma unroll
+			for (int i = 0; i < L; i++) acc[L] = __mul24(co[i], own[i]) + acc[L];
+			int g = 0;
+#pragma unroll
+			for (int r = 0; r <= L; r++) g += acc[r];
+			const bool interior = y >= 3 && y < height && x >= 3 && x < width - 3;   // vfgs_fw.c:470
+			g = interior ? (g + rnd) >> scale : 0;                                   // vfgs_fw.c:488
+			out = clip127(g + nz);
+#pragma unroll
+			for (int i = L - 1; i > 0; i--) own[i] = own[i - 1];
+			own[0] = out;
+			const bool valid = x >= 0 && x < width && y < height;
+			// next step's operands, all written long ago (or never: the noise)
+			int yn, xn;
+			coords(t + 1, yn, xn);
+			const int nz_next = buf[at(yn, xn)];
+#pragma unroll
+			for (int r = 1; r < L; r++) pre[r] = buf[at(yn - r - 1, xn + L)];
+			if (valid) buf[y * width + x] = (int8_t)out;
+			nz = nz_next;
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void fw_ar_kernel(FwLaunch L)
 {
 	const vfgs_hip_pattern_job& jb = L.job[blockIdx.x];
 	if (jb.kind != 1) return;
-	__shared__ int8_t buf[82 * 73];
+	__shared__ int8_t buf[82 * 73 + 2];
 	__shared__ int8_t G[2048];
 	__shared__ uint32_t W[kFwStreamWords];
-	const int lane = threadIdx.x;
+	const int tid = threadIdx.x;
 	const int sub = jb.chroma ? 2 : 1;
 	const int width = sub > 1 ? 44 : 82, height = sub > 1 ? 38 : 73;   // vfgs_fw.c:423-424
-	const int scale = jb.scale, shift = jb.shift;
+	const int shift = jb.shift;
 
-	for (int i = lane; i < 512; i += 64) ((uint32_t*)G)[i] = ((const uint32_t*)L.k->gauss)[i];
-	for (int i = lane; i < kFwStreamWords; i += 64) W[i] = L.k->stream[jb.seed_index][i];
-	int c[28];
-	for (int i = 0; i < 28; i++) c[i] = jb.coef[i];
+	// four wavefronts prepare (and later store); the recursion itself is one wavefront's work
+	for (int i = tid; i < 512; i += 256) ((uint32_t*)G)[i] = ((const uint32_t*)L.k->gauss)[i];
+	for (int i = tid; i < kFwStreamWords; i += 256) W[i] = L.k->stream[jb.seed_index][i];
+	__syncthreads();
+	// the noise term of every sample (vfgs_fw.c:492-493): one generator step per sample in raster order
+	for (int n = tid; n < width * height; n += 256)
+		buf[n] = (int8_t)(((int)G[noise_index(W, n)] + (1 << (shift - 1))) >> shift);
 	__syncthreads();
 
-	const int steps = width + 4 * (height - 1);
-	for (int t = 0; t < steps; t++)
+	// lag = how far the taps reach (rows above / columns to either side)
+	int lag = 1;
+	for (int j = 0; j < 4; j++)
+		for (int i = 0; i < 7; i++)
+			if (jb.coef[j * 7 + i] && !(j == 3 && i >= 3))
+				lag = max(lag, max(3 - j, abs(i - 3)));
+	if (tid < 64)
 	{
-		const int y = (t >> 2) - lane;
-		const int x = t - 4 * y;             // = (t & 3) + 4 * lane
-		if (y >= 0 && y < height && x < width)
-		{
-			int g = 0;
-			if (y >= 3 && x >= 3 && x < width - 3)                     // vfgs_fw.c:470
-			{
-				const int8_t* p = buf + width * y + x;
-#pragma unroll
-				for (int j = -3; j <= 0; j++)
-#pragma unroll
-					for (int i = -3; i <= 3; i++)
-						if (i < 0 || j < 0)
-							g += c[(3 + j) * 7 + 3 + i] * (int)p[width * j + i];
-				g = (g + (1 << (scale - 1))) >> scale;                 // vfgs_fw.c:488
-			}
-			const int n = y * width + x;                               // generator steps taken before this sample
-			g += ((int)G[noise_index(W, n)] + (1 << (shift - 1))) >> shift;   // vfgs_fw.c:492
-			buf[n] = (int8_t)clip127(g);
-		}
-		__syncthreads();   // one wavefront: orders this step's LDS writes before the next step's reads
+		if (lag == 1) ar_rows<1>(buf, jb.coef, width, height, jb.scale, tid);
+		else if (lag == 2) ar_rows<2>(buf, jb.coef, width, height, jb.scale, tid);
+		else ar_rows<3>(buf, jb.coef, width, height, jb.scale, tid);
 	}
+	__syncthreads();
 
 	// crop (vfgs_fw.c:498-501)
 	const int n = 64 / sub, off = 3 + 6 / sub;
-	for (int o = lane; o < n * n; o += 64)
+	for (int o = tid; o < n * n; o += 256)
 	{
 		const int y = o / n, x = o % n;
 		put_sample(L, jb, y, x, buf[width * (off + y) + off + x]);
@@ -215,8 +318,8 @@ hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream)
 		(L.job[i].kind ? ar : ff) = true;
 		chroma = chroma || L.job[i].chroma;
 	}
-	if (ff) hipLaunchKernelGGL(fw_ff_kernel, dim3(L.njobs), dim3(256), 0, stream, L);
-	if (ar) hipLaunchKernelGGL(fw_ar_kernel, dim3(L.njobs), dim3(64), 0, stream, L);
+	if (ff) hipLaunchKernelGGL(fw_ff_kernel, dim3(L.njobs), dim3(1024), 0, stream, L);
+	if (ar) hipLaunchKernelGGL(fw_ar_kernel, dim3(L.njobs), dim3(256), 0, stream, L);
 	if (chroma && !(L.csubx == 2 && L.csuby == 2))
 		hipLaunchKernelGGL(fw_commit_chroma, dim3(L.njobs), dim3(256), 0, stream, L);
 	return hipGetLastError();

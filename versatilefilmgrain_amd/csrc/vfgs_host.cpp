@@ -92,7 +92,8 @@ uint32_t lfsr_step(uint32_t r)
 class StreamCache {
 public:
 	static constexpr int kSlots = 4;
-	static constexpr uint64_t kMinWords = 1u << 18;  // 1 MiB of stream per refill = 64 frames of 4320p
+	static constexpr uint64_t kMaxRefill = 1u << 18; // 1 MiB of stream per refill = 64 frames of 4320p
+	static constexpr uint64_t kFirstRefill = 1u << 12;
 
 	void reseed(uint32_t reg)
 	{
@@ -100,6 +101,9 @@ public:
 		ck_word_ = 0;
 		ck_reg_ = reg;
 		cur_ = -1;   // nothing valid; slots keep their allocations
+		// A new seed per frame is the normal case for AFGS1 (vfgs_fw.c:672), so the first window after a
+		// reseed is only as large as the call needs; a stream that keeps being consumed grows its refills.
+		refill_ = kFirstRefill;
 	}
 
 	// register after `bit` steps
@@ -127,7 +131,8 @@ public:
 		if (cur_ >= 0 && wlo >= slot_[cur_].wbase && whi <= slot_[cur_].wbase + slot_[cur_].nwords)
 			return hipSuccess;
 		const uint32_t reg0 = window(wlo << 5);
-		const uint64_t n = std::max<uint64_t>(kMinWords, 2 * (whi - wlo));
+		const uint64_t n = std::max<uint64_t>(refill_, 2 * (whi - wlo));
+		refill_ = std::min<uint64_t>(refill_ * 4, kMaxRefill);
 		const int nxt = (cur_ < 0 ? last_ + 1 : cur_ + 1) % kSlots;
 		Slot& s = slot_[nxt];
 		hipError_t e;
@@ -137,9 +142,10 @@ public:
 			if (s.host) (void)hipHostFree(s.host);
 			if (s.dev) (void)hipFree(s.dev);
 			s.host = nullptr; s.dev = nullptr; s.cap = 0;
-			if ((e = hipHostMalloc((void**)&s.host, n * 4, hipHostMallocDefault)) != hipSuccess) return e;
-			if ((e = hipMalloc((void**)&s.dev, n * 4)) != hipSuccess) return e;
-			s.cap = n;
+			const uint64_t cap = std::max<uint64_t>(n, kMaxRefill);   // allocate once, whatever the refill size
+			if ((e = hipHostMalloc((void**)&s.host, cap * 4, hipHostMallocDefault)) != hipSuccess) return e;
+			if ((e = hipMalloc((void**)&s.dev, cap * 4)) != hipSuccess) return e;
+			s.cap = cap;
 		}
 		if (!s.ev && (e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)) != hipSuccess) return e;
 		// 32 words bit by bit, then W[n] = W[n-31] ^ W[n-3] (valid from word 32 of any base)
@@ -186,6 +192,7 @@ private:
 	};
 	Slot slot_[kSlots];
 	int cur_ = -1, last_ = -1;
+	uint64_t refill_ = kFirstRefill;
 	uint32_t seed_reg_ = 0xdeadbeefu;   // register at bit 0 (vfgs_hw.c:52-55 power-on value)
 	uint64_t ck_word_ = 0;              // a known (word, register) point to step from
 	uint32_t ck_reg_ = 0xdeadbeefu;
@@ -260,9 +267,10 @@ struct State {
 	int8_t* dev_bank = nullptr;               // [2][kSlots][64][64]
 	int8_t* dev_raw = nullptr;                // [kSlots][32*32]
 	vfgs::FwConstants* fw_const = nullptr;    // device copy of the model constants + noise streams
-	hipEvent_t fw_ev = nullptr;               // after the last generation (own_stream)
-	hipEvent_t patch_ev = nullptr;            // after the last kernel that read dev_bank
-	bool patch_seen = false;
+	std::vector<vfgs::FwLaunch> fw_pending;   // generation requests not yet launched (they run on the next grain call's stream)
+	hipStream_t bank_stream = nullptr;        // stream of the last kernels that touched dev_bank
+	hipEvent_t bank_ev = nullptr;             // ... and their completion, for the (rare) change of stream
+	bool bank_used = false;
 
 	// ---- look-ahead of the line API (see line_call()) -----------------------------------
 	uint64_t gen = 0;                 // bumped by every call that changes state other than a line call
@@ -329,6 +337,102 @@ int ensure_init(int device)
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// pattern generation on the device
+
+int fw_prepare(State& s)
+{
+	if (s.fw_const) return 0;
+	if ((size_t)(vfgs_fw_blob_end - vfgs_fw_blob) != 7168)
+		return fail(30, "embedded model tables have the wrong size");
+	std::vector<uint8_t> img(sizeof(vfgs::FwConstants));
+	memcpy(img.data(), vfgs_fw_blob, 7168);
+	vfgs::FwConstants* k = (vfgs::FwConstants*)img.data();
+	for (int i = 0; i < vfgs::kFwSeeds; i++)
+	{
+		// the firmware's generator (vfgs_fw.c:284-295) is the hardware layer's LFSR: stream word w
+		// is the register after 32*w steps, from word 32 on W[n] = W[n-31] ^ W[n-3]
+		uint32_t reg = k->seed[i];
+		for (int w = 0; w < vfgs::kFwStreamWords; w++)
+		{
+			if (w < 32) { k->stream[i][w] = reg; for (int b = 0; b < 32; b++) reg = lfsr_step(reg); }
+			else k->stream[i][w] = k->stream[i][w - 31] ^ k->stream[i][w - 3];
+		}
+	}
+	HIP_TRY(hipMalloc((void**)&s.fw_const, sizeof(vfgs::FwConstants)));
+	HIP_TRY(hipMemcpy(s.fw_const, img.data(), img.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMalloc((void**)&s.dev_bank, 2 * vfgs::kSlots * 4096));
+	HIP_TRY(hipMemset(s.dev_bank, 0, 2 * vfgs::kSlots * 4096));
+	HIP_TRY(hipMalloc((void**)&s.dev_raw, vfgs::kSlots * 1024));
+	HIP_TRY(hipEventCreateWithFlags(&s.bank_ev, hipEventDisableTiming));
+	return 0;
+}
+
+// dev_bank is about to be used by kernels on `stream`.  All of its users normally sit on one
+// stream and are ordered by it; only when the caller moves to another stream does the new one
+// wait for the old one's last use.
+int fw_bank_stream(State& s, hipStream_t stream)
+{
+	if (s.bank_used && s.bank_stream != stream)
+	{
+		HIP_TRY(hipEventRecord(s.bank_ev, s.bank_stream));
+		HIP_TRY(hipStreamWaitEvent(stream, s.bank_ev, 0));
+	}
+	s.bank_stream = stream;
+	s.bank_used = true;
+	return 0;
+}
+
+// Generation requests are only recorded when they are made (the firmware interface has no
+// stream, and needs no device until grain is actually added); they are launched here, on the
+// stream of the grain call that first needs the patterns, so plain stream order makes them
+// visible and a configuration switch costs no cross-stream synchronisation.
+int fw_flush(State& s, hipStream_t stream)
+{
+	if (s.fw_pending.empty()) return 0;
+	if (int e = fw_prepare(s)) return e;
+	if (int e = fw_bank_stream(s, stream)) return e;
+	for (vfgs::FwLaunch& L : s.fw_pending)
+	{
+		L.k = s.fw_const; L.bank = s.dev_bank; L.chroma_raw = s.dev_raw;
+		HIP_TRY(vfgs::launch_fw_generate(L, stream));
+	}
+	s.fw_pending.clear();
+	return 0;
+}
+
+int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
+{
+	State& s = S();
+	if (n <= 0) return 0;
+	if (n > vfgs::kFwMaxJobs) return fail(31, "vfgs_hip_generate_patterns: %d jobs (at most %d)", n, vfgs::kFwMaxJobs);
+	vfgs::FwLaunch L{};
+	L.last_luma = -1;
+	bool seen_chroma = false;
+	for (int i = 0; i < n; i++)
+	{
+		const vfgs_hip_pattern_job& j = jobs[i];
+		if (j.index < 0 || j.index >= vfgs::kSlots) return fail(20, "pattern job %d: slot %d", i, j.index);
+		if (j.seed_index < 0 || j.seed_index >= vfgs::kFwSeeds) return fail(32, "pattern job %d: seed index %d", i, j.seed_index);
+		if (j.kind == 0) { if (j.fh > 32767 || j.fv > 32767 || j.fh < -32768 || j.fv < -32768) return fail(33, "pattern job %d: cut-off out of int16 range", i); }
+		else if (j.kind == 1) { if (j.scale < 1 || j.scale > 15 || j.shift < 1 || j.shift > 7) return fail(34, "pattern job %d: scale %d / shift %d", i, j.scale, j.shift); }
+		else return fail(35, "pattern job %d: kind %d", i, j.kind);
+		if (j.chroma) seen_chroma = true;
+		else { if (seen_chroma) return fail(36, "pattern jobs: luma jobs must come first"); L.last_luma = j.index; }
+		L.job[i] = j;
+	}
+	L.njobs = n; L.csubx = s.csubx; L.csuby = s.csuby;   // the layout at the time of the call, as vfgs_hw.c:320-325
+	if (s.fw_pending.size() >= 64)
+	{   // nobody added grain for 64 configurations: run them now rather than queue without bound
+		if (int e = ensure_init(-1)) return e;
+		if (int e = fw_flush(s, s.own_stream)) return e;
+	}
+	s.fw_pending.push_back(L);
+	for (int i = 0; i < n; i++) s.dev_origin[jobs[i].chroma ? 1 : 0] |= 1u << jobs[i].index;
+	s.tables_dirty = true;
+	return 0;
+}
+
 // Build the slot-interleaved LDS image of vfgs_layout.h from the mirror.
 template <int CSUBX, int CSUBY>
 void build_tables(const State& s, std::vector<uint8_t>& img)
@@ -369,6 +473,7 @@ int upload_tables(State& s, hipStream_t stream)
 	if (!s.tables_dirty && s.tables_ring.current())
 		return 0;
 	if (int e = check_luts(s)) return e;
+	if (int e = fw_flush(s, stream)) return e;
 	void* dst = nullptr;
 	const int bytes = vfgs::table_bytes(s.csubx, s.csuby);
 	HIP_TRY(s.tables_ring.next(bytes, &dst));
@@ -381,76 +486,10 @@ int upload_tables(State& s, hipStream_t stream)
 	if (s.dev_origin[0] | s.dev_origin[1])
 	{
 		// device-generated slots never visit the host: copy them bank -> image on the device
-		HIP_TRY(hipStreamWaitEvent(stream, s.fw_ev, 0));
+		if (int e = fw_bank_stream(s, stream)) return e;
 		HIP_TRY(vfgs::launch_fw_patch((uint8_t*)dst, s.dev_bank, s.dev_origin[0], s.dev_origin[1], s.csubx, s.csuby, stream));
-		HIP_TRY(hipEventRecord(s.patch_ev, stream));
-		s.patch_seen = true;
 	}
 	s.tables_dirty = false;
-	return 0;
-}
-
-// ------------------------------------------------------------------------------------
-// pattern generation on the device
-
-int fw_prepare(State& s)
-{
-	if (s.fw_const) return 0;
-	if ((size_t)(vfgs_fw_blob_end - vfgs_fw_blob) != 7168)
-		return fail(30, "embedded model tables have the wrong size");
-	std::vector<uint8_t> img(sizeof(vfgs::FwConstants));
-	memcpy(img.data(), vfgs_fw_blob, 7168);
-	vfgs::FwConstants* k = (vfgs::FwConstants*)img.data();
-	for (int i = 0; i < vfgs::kFwSeeds; i++)
-	{
-		// the firmware's generator (vfgs_fw.c:284-295) is the hardware layer's LFSR: stream word w
-		// is the register after 32*w steps, from word 32 on W[n] = W[n-31] ^ W[n-3]
-		uint32_t reg = k->seed[i];
-		for (int w = 0; w < vfgs::kFwStreamWords; w++)
-		{
-			if (w < 32) { k->stream[i][w] = reg; for (int b = 0; b < 32; b++) reg = lfsr_step(reg); }
-			else k->stream[i][w] = k->stream[i][w - 31] ^ k->stream[i][w - 3];
-		}
-	}
-	HIP_TRY(hipMalloc((void**)&s.fw_const, sizeof(vfgs::FwConstants)));
-	HIP_TRY(hipMemcpy(s.fw_const, img.data(), img.size(), hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc((void**)&s.dev_bank, 2 * vfgs::kSlots * 4096));
-	HIP_TRY(hipMemset(s.dev_bank, 0, 2 * vfgs::kSlots * 4096));
-	HIP_TRY(hipMalloc((void**)&s.dev_raw, vfgs::kSlots * 1024));
-	HIP_TRY(hipEventCreateWithFlags(&s.fw_ev, hipEventDisableTiming));
-	HIP_TRY(hipEventCreateWithFlags(&s.patch_ev, hipEventDisableTiming));
-	return 0;
-}
-
-int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
-{
-	State& s = S();
-	if (n <= 0) return 0;
-	if (n > vfgs::kFwMaxJobs) return fail(31, "vfgs_hip_generate_patterns: %d jobs (at most %d)", n, vfgs::kFwMaxJobs);
-	vfgs::FwLaunch L{};
-	L.last_luma = -1;
-	bool seen_chroma = false;
-	for (int i = 0; i < n; i++)
-	{
-		const vfgs_hip_pattern_job& j = jobs[i];
-		if (j.index < 0 || j.index >= vfgs::kSlots) return fail(20, "pattern job %d: slot %d", i, j.index);
-		if (j.seed_index < 0 || j.seed_index >= vfgs::kFwSeeds) return fail(32, "pattern job %d: seed index %d", i, j.seed_index);
-		if (j.kind == 0) { if (j.fh > 32767 || j.fv > 32767 || j.fh < -32768 || j.fv < -32768) return fail(33, "pattern job %d: cut-off out of int16 range", i); }
-		else if (j.kind == 1) { if (j.scale < 1 || j.scale > 15 || j.shift < 1 || j.shift > 7) return fail(34, "pattern job %d: scale %d / shift %d", i, j.scale, j.shift); }
-		else return fail(35, "pattern job %d: kind %d", i, j.kind);
-		if (j.chroma) seen_chroma = true;
-		else { if (seen_chroma) return fail(36, "pattern jobs: luma jobs must come first"); L.last_luma = j.index; }
-		L.job[i] = j;
-	}
-	if (int e = ensure_init(-1)) return e;
-	if (int e = fw_prepare(s)) return e;
-	L.k = s.fw_const; L.bank = s.dev_bank; L.chroma_raw = s.dev_raw;
-	L.njobs = n; L.csubx = s.csubx; L.csuby = s.csuby;
-	if (s.patch_seen) HIP_TRY(hipStreamWaitEvent(s.own_stream, s.patch_ev, 0));   // earlier images may still be assembling
-	HIP_TRY(vfgs::launch_fw_generate(L, s.own_stream));
-	HIP_TRY(hipEventRecord(s.fw_ev, s.own_stream));
-	for (int i = 0; i < n; i++) s.dev_origin[jobs[i].chroma ? 1 : 0] |= 1u << jobs[i].index;
-	s.tables_dirty = true;
 	return 0;
 }
 
@@ -944,6 +983,7 @@ void vfgs_hip_reset_state(void)
 	memset(s.slut, 0, sizeof s.slut);
 	memset(s.plut, 0, sizeof s.plut);
 	s.dev_origin[0] = s.dev_origin[1] = 0;
+	s.fw_pending.clear();
 	s.scale_shift = 5 + 6;
 	s.bs = 0;
 	s.ymin = s.cmin = 0;
@@ -965,6 +1005,7 @@ void vfgs_hip_shutdown(void)
 	std::lock_guard<std::mutex> g(g_mu);
 	State& s = S();
 	if (!s.inited) return;
+	(void)fw_flush(s, s.own_stream);
 	(void)hipDeviceSynchronize();
 	// device-generated patterns move to the host mirror so the programmed state survives
 	for (int c = 0; c < 2; c++)
@@ -984,10 +1025,9 @@ void vfgs_hip_shutdown(void)
 	if (s.fw_const) (void)hipFree(s.fw_const);
 	if (s.dev_bank) (void)hipFree(s.dev_bank);
 	if (s.dev_raw) (void)hipFree(s.dev_raw);
-	if (s.fw_ev) (void)hipEventDestroy(s.fw_ev);
-	if (s.patch_ev) (void)hipEventDestroy(s.patch_ev);
-	s.fw_const = nullptr; s.dev_bank = nullptr; s.dev_raw = nullptr; s.fw_ev = s.patch_ev = nullptr;
-	s.patch_seen = false;
+	if (s.bank_ev) (void)hipEventDestroy(s.bank_ev);
+	s.fw_const = nullptr; s.dev_bank = nullptr; s.dev_raw = nullptr; s.bank_ev = nullptr;
+	s.bank_used = false; s.bank_stream = nullptr;
 	s.dev_origin[0] = s.dev_origin[1] = 0;
 	if (s.own_stream) (void)hipStreamDestroy(s.own_stream);
 	if (s.ev0) (void)hipEventDestroy(s.ev0);
@@ -1105,6 +1145,9 @@ int vfgs_hip_get_pattern(int chroma, int index, signed char out[64 * 64])
 	if (chroma < 0 || chroma > 1 || index < 0 || index >= vfgs::kSlots) return fail(20, "vfgs_hip_get_pattern: bank %d slot %d", chroma, index);
 	if (s.dev_origin[chroma] >> index & 1)
 	{
+		if (int e = ensure_init(-1)) return e;
+		if (int e = fw_flush(s, s.own_stream)) return e;
+		if (int e = fw_bank_stream(s, s.own_stream)) return e;
 		HIP_TRY(hipStreamSynchronize(s.own_stream));
 		HIP_TRY(hipMemcpy(out, s.dev_bank + (size_t)(chroma * vfgs::kSlots + index) * 4096, 4096, hipMemcpyDeviceToHost));
 	}
