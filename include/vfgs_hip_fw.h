@@ -106,6 +106,35 @@ int vfgs_hip_generate_patterns(const vfgs_hip_pattern_job* jobs, int n);
  * holds it ([64][64], vfgs_hw.c:49).  Synchronises; for tests and debugging. */
 int vfgs_hip_get_pattern(int chroma, int index, signed char out[64 * 64]);
 
+/* ---- configuration files ----------------------------------------
+ * What the reference CLI does between `-c <file>` and vfgs_init_* (vfgs_main.c:126-195 value
+ * readers, :208-232 chroma adjustment, :234-303 checks, :309-434 AFGS1 "grain table" syntax,
+ * :436-559 cfg and SEI-dump syntaxes, :561-593 gain), as library calls, so that a host without
+ * the reference's vfgs_main.c can go from a configuration file to a programmed device.  Host
+ * only; no GPU needed until vfgs_hip_cfg_program().
+ *
+ * The state is the pair of parameter sets the CLI keeps (vfgs_main.c:69-124).  Reading a file
+ * updates it IN PLACE -- fields a file does not mention keep their previous values, exactly as
+ * in the CLI, where every file is read on top of the defaults / the previous configuration.
+ * AFGS1 is active when afgs1.num_y_points != 0 (vfgs_main.c:297-303). */
+typedef struct vfgs_hip_cfg {
+	fgs_sei sei;
+	fgs_afgs1 afgs1;
+} vfgs_hip_cfg;
+
+/* the CLI's built-in SEI (vfgs_main.c:69-120), AFGS1 off */
+void vfgs_hip_cfg_defaults(vfgs_hip_cfg* cfg);
+/* read one file (any of the three syntaxes); 0, or 1 with the reference's message in vfgs_hip_last_error_string() */
+int vfgs_hip_cfg_read(vfgs_hip_cfg* cfg, const char* filename);
+/* the CLI's acceptance checks for picture format 420 / 422 / 444 and bit depth 8 / 10; 0 or 1 + message */
+int vfgs_hip_cfg_check(const vfgs_hip_cfg* cfg, int format, int depth);
+/* SEI frequency cut-offs and scale of the chroma components for subsampled formats (vfgs_main.c:208-232) */
+void vfgs_hip_cfg_adjust_chroma(vfgs_hip_cfg* cfg, int format);
+/* global strength in percent (vfgs_main.c:561-593); 100 = unchanged */
+void vfgs_hip_cfg_apply_gain(vfgs_hip_cfg* cfg, unsigned gain);
+/* vfgs_init_afgs1(&cfg->afgs1) or vfgs_init_sei(&cfg->sei), whichever is active (vfgs_main.c:757-760) */
+void vfgs_hip_cfg_program(vfgs_hip_cfg* cfg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,9 @@ int main(void)
 		(void (*)(void))vfgs_hip_last_error_string, (void (*)(void))vfgs_hip_timer_begin, (void (*)(void))vfgs_hip_timer_end, (void (*)(void))vfgs_hip_device_info,
 		/* firmware interface, vfgs_fw.h:91-92, and its extensions */
 		(void (*)(void))vfgs_init_sei, (void (*)(void))vfgs_init_afgs1, (void (*)(void))vfgs_hip_generate_patterns, (void (*)(void))vfgs_hip_get_pattern,
+		/* configuration files */
+		(void (*)(void))vfgs_hip_cfg_defaults, (void (*)(void))vfgs_hip_cfg_read, (void (*)(void))vfgs_hip_cfg_check,
+		(void (*)(void))vfgs_hip_cfg_adjust_chroma, (void (*)(void))vfgs_hip_cfg_apply_gain, (void (*)(void))vfgs_hip_cfg_program,
 	};
 	unsigned char lut[256] = {0};
 	signed char pat[64 * 64] = {0};

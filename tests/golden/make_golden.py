@@ -51,7 +51,18 @@ NON_420 = [  # (cfg, depth, fmt): driven with --no-check (vfgs_main.c:235 reject
     ("fgs_afgs1_test3", 10, "422"),
 ]
 
+# the two other file syntaxes the CLI reads (vfgs_main.c:309-434 grain table, :490-514 SEI dump)
+OTHER_SYNTAX = [("fgs_afgs1_test1.tbl", 10, "420"), ("fgs_afgs1_test1.tbl", 8, "420"), ("fgs_sei_dump.txt", 10, "420")]
+
 SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1)}
+
+
+def cfg_path(cfg):
+    return CFG / (cfg if "." in cfg else f"{cfg}.cfg")
+
+
+def job_name(cfg, depth, fmt):
+    return f"{(cfg or 'default').replace('.', '_')}_{depth}_{fmt}"
 
 
 def write_input(path, w, h, depth, fmt, nframes):
@@ -71,7 +82,7 @@ def run_ref(w, h, depth, fmt, cfg, nframes, inp, out, outdepth=None):
     if fmt != "420":
         cmd.append("--no-check")
     if cfg:
-        cmd += ["-c", str(CFG / f"{cfg}.cfg")]
+        cmd += ["-c", str(cfg_path(cfg))]
     cmd += [inp, out]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
     return hashlib.md5(Path(out).read_bytes()).hexdigest()
@@ -84,7 +95,7 @@ def record_trace(depth, fmt, cfg, dst):
     if fmt == "420":
         cmd.remove("--no-check")
     if cfg:
-        cmd += ["-c", str(CFG / f"{cfg}.cfg")]
+        cmd += ["-c", str(cfg_path(cfg))]
     env = dict(os.environ, VFGS_TRACE_OUT=tname)
     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     T.save_trace_npz(T.parse_trace_file(tname), dst)
@@ -100,7 +111,7 @@ def record_fwcfg(depth, fmt, cfg, dst):
     if fmt == "420":
         cmd.remove("--no-check")
     if cfg:
-        cmd += ["-c", str(CFG / f"{cfg}.cfg")]
+        cmd += ["-c", str(cfg_path(cfg))]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     raw = Path(tname).read_bytes()
     os.unlink(tname)
@@ -116,16 +127,42 @@ def record_fwcfg(depth, fmt, cfg, dst):
 def fwcfg_only():
     (T.GOLDEN / "fwcfg").mkdir(parents=True, exist_ok=True)
     cfgs = sorted(p.stem for p in CFG.glob("*.cfg"))
-    jobs = [(c, d, "420") for c in [None] + cfgs for d in (8, 10)] + NON_420
+    jobs = [(c, d, "420") for c in [None] + cfgs for d in (8, 10)] + NON_420 + OTHER_SYNTAX
     for cfg, depth, fmt in jobs:
-        name = f"{cfg or 'default'}_{depth}_{fmt}"
+        name = job_name(cfg, depth, fmt)
         record_fwcfg(depth, fmt, cfg, T.GOLDEN / "fwcfg" / f"{name}.npz")
         print("fwcfg", name, flush=True)
+
+
+def cfg_corpus():
+    """The configuration files themselves (INPUT data of the cfg reader tests), as one archive."""
+    files = sorted(p for p in CFG.iterdir() if p.suffix in (".cfg", ".tbl", ".txt"))
+    np.savez_compressed(T.GOLDEN / "cfg_corpus.npz", **{p.name: np.frombuffer(p.read_bytes(), dtype=np.uint8) for p in files})
+    print("cfg corpus:", len(files), "files")
+
+
+def extras_only():
+    """Add the grain-table / SEI-dump command lines to the existing fixtures without redoing the rest."""
+    w, h, n = SMALL
+    md5 = json.loads((T.GOLDEN / "md5.json").read_text())
+    with tempfile.TemporaryDirectory() as tmp:
+        for cfg, depth, fmt in OTHER_SYNTAX:
+            name = job_name(cfg, depth, fmt)
+            inp, out = f"{tmp}/in.yuv", f"{tmp}/out.yuv"
+            write_input(inp, w, h, depth, fmt, n)
+            record_trace(depth, fmt, cfg, T.TRACES / f"{name}.npz")
+            record_fwcfg(depth, fmt, cfg, T.GOLDEN / "fwcfg" / f"{name}.npz")
+            md5["small"][name] = run_ref(w, h, depth, fmt, cfg, n, inp, out)
+            print(name, md5["small"][name], flush=True)
+    (T.GOLDEN / "md5.json").write_text(json.dumps(md5, indent=1, sort_keys=True) + "\n")
+    cfg_corpus()
 
 
 def main():
     if "--fwcfg-only" in sys.argv:
         return fwcfg_only()
+    if "--extras-only" in sys.argv:
+        return extras_only()
     T.build_oracle()
     (T.GOLDEN / "traces").mkdir(parents=True, exist_ok=True)
     (T.GOLDEN / "frames").mkdir(parents=True, exist_ok=True)
@@ -142,9 +179,9 @@ def main():
                 inputs[(depth, fmt)] = p
                 md5["inputs"][f"{w}x{h}_{depth}_{fmt}_x{n}"] = hashlib.md5(Path(p).read_bytes()).hexdigest()
 
-        jobs = [(c, d, "420") for c in [None] + cfgs for d in (8, 10)] + NON_420
+        jobs = [(c, d, "420") for c in [None] + cfgs for d in (8, 10)] + NON_420 + OTHER_SYNTAX
         for cfg, depth, fmt in jobs:
-            name = f"{cfg or 'default'}_{depth}_{fmt}"
+            name = job_name(cfg, depth, fmt)
             record_trace(depth, fmt, cfg, T.TRACES / f"{name}.npz")
             (T.GOLDEN / "fwcfg").mkdir(parents=True, exist_ok=True)
             record_fwcfg(depth, fmt, cfg, T.GOLDEN / "fwcfg" / f"{name}.npz")
@@ -173,6 +210,7 @@ def main():
             os.unlink(out)
 
     (T.GOLDEN / "md5.json").write_text(json.dumps(md5, indent=1, sort_keys=True) + "\n")
+    cfg_corpus()
 
 
 if __name__ == "__main__":

@@ -268,3 +268,41 @@ def test_reference_cli_with_our_firmware_and_hardware_layer(hip, tmp_path):
             assert len(outs[0]) == len(inp.read_bytes())
             assert outs[0] != inp.read_bytes()          # grain was really added
             assert outs[0] == outs[1], cfgs
+
+
+# ---------------------------------------------------------------------------------------
+# the whole chain without any reference code: cfg FILE -> vfgs_hip_cfg_* -> firmware on the GPU
+# -> hardware layer, against the reference CLI's md5 for the same command line
+
+@pytest.fixture(scope="module")
+def corpus(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cfg")
+    with np.load(T.GOLDEN / "cfg_corpus.npz") as z:
+        for name in z.files:
+            (d / name).write_bytes(z[name].tobytes())
+    return d
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if n.endswith("_420")])
+def test_cfg_file_through_library_equals_reference_cli_md5(hip, corpus, name):
+    from test_cfg_cpu import split_name
+    from versatilefilmgrain_amd import fw
+    file, depth, fmt = split_name(name)
+    seed, _ = T.load_fwcfg(name)
+    hip.lib.vfgs_hip_reset_state()
+    hip.set_depth(depth)                       # vfgs_main.c:750-760
+    hip.set_chroma_subsampling(2, 2)
+    st = fw.Cfg.defaults()
+    assert st.check(fmt, depth) == 0
+    st.adjust_chroma(fmt)
+    st.apply_gain(100)
+    st.program()
+    hip.set_seed(seed)
+    if file is not None and st.read(corpus / file) == 0 and st.check(fmt, depth) == 0:   # vfgs_main.c:773-781
+        st.adjust_chroma(fmt)
+        st.apply_gain(100)
+        st.program()
+    frames, _ = T.lcg_frames(W, H, depth, 2, 2, N)
+    for f in frames:
+        host_frame_call(hip, f)
+    assert T.md5_frames(frames) == MD5["small"][name]

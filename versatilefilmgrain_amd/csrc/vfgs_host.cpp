@@ -867,6 +867,11 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 
 }  // namespace
 
+namespace vfgs {
+// for the other host files of the library (vfgs_cfg_host.cpp): record an error like fail()
+int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+}
+
 // ========================================================================================
 // C ABI
 

@@ -12,7 +12,9 @@ from . import hw
 
 SEI_MAX_MODEL_VALUES = 6   # vfgs_fw.h:49
 
-EXPORTS = ["vfgs_init_sei", "vfgs_init_afgs1", "vfgs_hip_generate_patterns", "vfgs_hip_get_pattern"]
+EXPORTS = ["vfgs_init_sei", "vfgs_init_afgs1", "vfgs_hip_generate_patterns", "vfgs_hip_get_pattern",
+           "vfgs_hip_cfg_defaults", "vfgs_hip_cfg_read", "vfgs_hip_cfg_check", "vfgs_hip_cfg_adjust_chroma",
+           "vfgs_hip_cfg_apply_gain", "vfgs_hip_cfg_program"]
 
 
 class FgsSei(C.Structure):   # vfgs_fw.h:51-60
@@ -67,6 +69,37 @@ class PatternJob(C.Structure):   # vfgs_hip_pattern_job
     ]
 
 
+class Cfg(C.Structure):   # vfgs_hip_cfg: the CLI's configuration state (vfgs_main.c:69-124)
+    _fields_ = [("sei", FgsSei), ("afgs1", FgsAfgs1)]
+
+    @classmethod
+    def defaults(cls) -> "Cfg":
+        c = cls()
+        _lib().vfgs_hip_cfg_defaults(C.byref(c))
+        return c
+
+    def read(self, filename) -> int:
+        """0, or 1 (message: hw.load().vfgs_hip_last_error_string())."""
+        return _lib().vfgs_hip_cfg_read(C.byref(self), str(filename).encode())
+
+    def check(self, fmt: int, depth: int) -> int:
+        return _lib().vfgs_hip_cfg_check(C.byref(self), fmt, depth)
+
+    def adjust_chroma(self, fmt: int) -> None:
+        _lib().vfgs_hip_cfg_adjust_chroma(C.byref(self), fmt)
+
+    def apply_gain(self, gain: int) -> None:
+        _lib().vfgs_hip_cfg_apply_gain(C.byref(self), gain)
+
+    def program(self) -> None:
+        _lib().vfgs_hip_cfg_program(C.byref(self))
+
+    @property
+    def active(self):
+        """The parameter set vfgs_init_* would receive (vfgs_main.c:757-760)."""
+        return self.afgs1 if self.afgs1.num_y_points else self.sei
+
+
 def _lib():
     lib = hw.load()
     if not getattr(lib, "_fw_typed", False):
@@ -76,6 +109,16 @@ def _lib():
         lib.vfgs_init_afgs1.restype = None
         lib.vfgs_hip_generate_patterns.argtypes = [C.POINTER(PatternJob), C.c_int]
         lib.vfgs_hip_get_pattern.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        lib.vfgs_hip_cfg_defaults.argtypes = [C.POINTER(Cfg)]
+        lib.vfgs_hip_cfg_defaults.restype = None
+        lib.vfgs_hip_cfg_read.argtypes = [C.POINTER(Cfg), C.c_char_p]
+        lib.vfgs_hip_cfg_check.argtypes = [C.POINTER(Cfg), C.c_int, C.c_int]
+        lib.vfgs_hip_cfg_adjust_chroma.argtypes = [C.POINTER(Cfg), C.c_int]
+        lib.vfgs_hip_cfg_adjust_chroma.restype = None
+        lib.vfgs_hip_cfg_apply_gain.argtypes = [C.POINTER(Cfg), C.c_uint]
+        lib.vfgs_hip_cfg_apply_gain.restype = None
+        lib.vfgs_hip_cfg_program.argtypes = [C.POINTER(Cfg)]
+        lib.vfgs_hip_cfg_program.restype = None
         lib._fw_typed = True
     return lib
 
