@@ -603,12 +603,18 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		const unsigned tunits = 2 * nblk + 1;
 		a.segs_y = (int)((tunits + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits);
 		a.upt_y = (int)(2 * ((tunits + 2 * a.segs_y - 1) / (2 * a.segs_y)));
+#ifdef VFGS_FULL_SEGMENTS          // tools/ablate.py knob: 1 KiB segments, the last one mostly empty (measured: no difference)
+		a.upt_y = vfgs::kMaxUnits;
+#endif
 		a.tiles_y = (a.segs_y + 3) / 4;
 		if (s.csubx == 2)
 		{   // 8-sample chroma blocks: one lane per block edge m = 0 .. nblk
 			const unsigned tedges = nblk + 1;
 			a.segs_c = (int)((tedges + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits);
 			a.upt_c = (int)((tedges + a.segs_c - 1) / a.segs_c);
+#ifdef VFGS_FULL_SEGMENTS
+			a.upt_c = vfgs::kMaxUnits;
+#endif
 			a.tiles_c = (a.segs_c + 3) / 4;
 		}
 		else { a.segs_c = a.segs_y; a.upt_c = a.upt_y; a.tiles_c = a.tiles_y; }

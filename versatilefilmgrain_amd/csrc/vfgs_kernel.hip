@@ -249,7 +249,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
                                             bool edge_on, bool first, int rel, int c0, int c1,
                                             int scale_shift, int half, uint32_t lo2, uint32_t hi2)
 {
-#if VFGS_ABLATE == 1
+#if VFGS_ABLATE == 1 || (VFGS_ABLATE >= 11 && VFGS_ABLATE <= 13)   // copy only (11: + no table staging, 12: + no LFSR loads, 13: both)
 	return;
 #endif
 	uint32_t e[8];
@@ -261,14 +261,24 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	{
 		const uint32_t idx = (DEPTH > 8) ? (w[k] & 0x03fc03fcu) : ((w[k] & 0x00ff00ffu) << 2);
 		const uint32_t lut = k < 2 ? lut0 : lut1;
+#if VFGS_ABLATE == 8 || VFGS_ABLATE == 10   // timing only: no LUT gather
+		e[2 * k]     = (idx << 22) | 37u | lut;
+		e[2 * k + 1] = (idx << 6) | 53u | lut;
+#else
 		e[2 * k]     = *(const uint32_t*)(lds + lut + (idx & 0xffffu));
 		e[2 * k + 1] = *(const uint32_t*)(lds + lut + (idx >> 16));
+#endif
 	}
 
 	// pattern fetch: 4 samples x 8 slots = 32 bytes per half
 	{
+#if VFGS_ABLATE == 9 || VFGS_ABLATE == 10    // timing only: no pattern fetch from LDS
+		const u32x4 c0_ = {a0, a1, a0 * 3, a1 * 5}, c1_ = {a0 ^ a1, a0 + a1, a0 * 7, a1 * 9};
+		const u32x4 c2_ = {a1, a0, a1 * 3, a0 * 5}, c3_ = {a1 ^ 77, a0 + 99, a1 * 7, a0 * 9};
+#else
 		const u32x4 c0_ = *(const u32x4*)(lds + a0), c1_ = *(const u32x4*)(lds + a0 + 16);
 		const u32x4 c2_ = *(const u32x4*)(lds + a1), c3_ = *(const u32x4*)(lds + a1 + 16);
+#endif
 		P[0] = pick_slot(c0_.y, c0_.x, e[0]); P[1] = pick_slot(c0_.w, c0_.z, e[1]);
 		P[2] = pick_slot(c1_.y, c1_.x, e[2]); P[3] = pick_slot(c1_.w, c1_.z, e[3]);
 		P[4] = pick_slot(c2_.y, c2_.x, e[4]); P[5] = pick_slot(c2_.w, c2_.z, e[5]);
@@ -446,14 +456,18 @@ __device__ __forceinline__ void plane_item(const KernelArgs& a, uint8_t* lds, ui
 			load_unit<DEPTH, SPLIT>(srs, vo0[g], vo1[g], 0, w[g]);
 		// LFSR stream slices of this block row (and the one above): lane l takes dword w0 + l; the
 		// windows of all blocks of the row lie inside the first (nblk + 63) / 32 dwords
+#if VFGS_ABLATE != 12 && VFGS_ABLATE != 13
 		sw[0] = a.stream[cur_w0 + lane];
 		sw[1] = a.stream[up_w0 + lane];
+#endif
 		return;
 	}
 
 	// ---- block parameters: windows out of the stream slices (via a per-wave LDS scratch) ------
+#if VFGS_ABLATE != 12 && VFGS_ABLATE != 13
 	*(uint32_t*)(lds + scratch + 4 * lane) = sw[0];
 	*(uint32_t*)(lds + scratch + 256 + 4 * lane) = sw[1];
+#endif
 	const int comp = d.plane;
 	const int fsx = comp == 0 ? 0 : (comp == 1 ? 10 : 20);
 	const int fsy = comp == 0 ? 14 : (comp == 1 ? 24 : 4);
@@ -473,13 +487,28 @@ __device__ __forceinline__ void plane_item(const KernelArgs& a, uint8_t* lds, ui
 		return __builtin_amdgcn_alignbit(hi, lo, bit & 31);
 	};
 
+#if VFGS_ABLATE == 7
+	BlockParam keep0, keep1;
+#endif
 #pragma unroll
 	for (int g = 0; g < 4; g++)
 	{
 		if (d.tile * 4 + g >= segs)
 			break;                                          // wave-uniform
+#if VFGS_ABLATE == 7   // timing only: block parameters of segment 0 reused for segments 1..3 (what sharing them would save)
+		static_assert(true, "");
+		BlockParam c0, c1;
+		if (g == 0)
+		{
+			c0 = block_param_rt<SUBX, SUBY, RS>(window(0, cur_w0, cur_bit + bl[g]), bank, fsx, fsy, fsb);
+			c1 = (BW == 16) ? c0 : block_param_rt<SUBX, SUBY, RS>(window(0, cur_w0, cur_bit + br[g]), bank, fsx, fsy, fsb);
+			keep0 = c0; keep1 = c1;
+		}
+		else { c0 = keep0; c1 = keep1; }
+#else
 		const BlockParam c0 = block_param_rt<SUBX, SUBY, RS>(window(0, cur_w0, cur_bit + bl[g]), bank, fsx, fsy, fsb);
 		const BlockParam c1 = (BW == 16) ? c0 : block_param_rt<SUBX, SUBY, RS>(window(0, cur_w0, cur_bit + br[g]), bank, fsx, fsy, fsb);
+#endif
 		uint32_t h0, h1;
 		if (BW == 16) { h0 = first[g] ? 0u : 8u * kSlots; h1 = h0 + 4 * kSlots; }
 		else { h0 = 4 * kSlots; h1 = 0; }                   // samples 4..7 of the left block, 0..3 of the right block
@@ -515,7 +544,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * kWGPerCU + 3) / 4)
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L::BYTES + kWavesPerWG * kScratch];
 
 	// stage banks + LUTs: global (L2 resident) -> LDS, 16 bytes per lane per step
-#if VFGS_ABLATE != 6
+#if VFGS_ABLATE != 6 && VFGS_ABLATE != 11 && VFGS_ABLATE != 13
 	for (int i = threadIdx.x * 16; i < L::BYTES; i += kWavesPerWG * 64 * 16)
 		*(u32x4*)(lds + i) = *(const u32x4*)(a.tables + i);
 	__syncthreads();

@@ -24,7 +24,9 @@ constexpr int kMaxUnits = 64;    // 8-sample units per work item row (one per la
 #define VFGS_PIPE 0       // 1: issue the next item's loads before computing the current item (two register sets)
 #endif
 #ifndef VFGS_ABLATE
-#define VFGS_ABLATE 0   // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py)
+#define VFGS_ABLATE 0   // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py):
+                        //   1 copy only, 5 no stores, 6 no table staging, 7 block parameters of segment 0 reused,
+                        //   8 no LUT gather, 9 no pattern fetch, 10 = 8 + 9, 11 = 1 + 6, 12 = 1 without LFSR loads, 13 = 11 + 12
 #endif
 constexpr int kWavesPerWG = VFGS_WAVES;     // waves per workgroup, one LDS image each
 constexpr int kWGPerCU = VFGS_WG_PER_CU;    // resident workgroups per CU the grid is sized for
