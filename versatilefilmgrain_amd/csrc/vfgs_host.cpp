@@ -577,6 +577,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 			return fail(8, "destination planes, pitches and frame pitches must be multiples of 16 bytes");
 	}
 	if (part_h == 0 || nframes == 0) return 0;
+	if (int e = check_luts(s)) return e;     // before any state moves: a refused call leaves the seed registers alone
 
 	const unsigned nblk = (width + 15) / 16;
 	const unsigned sz = s.bs ? 2 : 1;
