@@ -51,10 +51,36 @@ def main():
         fw.get_pattern(0, 0)
         r = {"patterns": sum(1 for op, *_ in rec if op in (T.OP_LUMA_PATTERN, T.OP_CHROMA_PATTERN)) -
              sum(1 for op, *_ in T.load_trace("default_10_420") if op in (T.OP_LUMA_PATTERN, T.OP_CHROMA_PATTERN))}
+        # a second, slightly different parameter set: alternating between the two defeats the
+        # "same request as last time" shortcut, so every switch really generates patterns
+        other = type(cfg).from_buffer_copy(bytes(cfg))
+        if kind:
+            other.ar_coeffs_y[0] += 1
+            other.ar_coeffs_cb[0] += 1
+            other.ar_coeffs_cr[0] += 1
+        else:
+            for c in range(3):
+                for k in range(other.num_intensity_intervals[c]):
+                    v = other.comp_model_value[c][k]
+                    if other.model_id:
+                        v[1] += 1
+                    else:
+                        v[1] = v[1] - 1 if v[1] > 8 else v[1] + 1
+
         # 1. our firmware: time until the call returns (everything queued) and until the patterns exist
-        r["hip_call_returns_ms"] = med(lambda: fw.init(cfg), 50)
+        flip = [0]
+
+        def call_only():
+            flip[0] ^= 1
+            fw.init(other if flip[0] else cfg)
+        r["hip_call_returns_ms"] = med(call_only, 50)
         torch.cuda.synchronize()
-        r["hip_patterns_ready_ms"] = med(lambda: (fw.init(cfg), fw.get_pattern(0, 0)), 50)
+
+        def gen_and_wait():
+            flip[0] ^= 1
+            fw.init(other if flip[0] else cfg)
+            fw.get_pattern(0, 0)
+        r["hip_patterns_ready_ms"] = med(gen_and_wait, 50)
         # 2. config switch before EVERY frame of a device-resident 1080p sequence
         Y = torch.randint(0, 1024, (8, H, W), dtype=torch.int16, device="cuda")
         U = torch.randint(0, 1024, (8, H // 2, W // 2), dtype=torch.int16, device="cuda")
@@ -66,6 +92,8 @@ def main():
             t0 = time.perf_counter()
             for i in range(n):
                 if switch == "device":
+                    fw.init(other if i & 1 else cfg)
+                elif switch == "same":
                     fw.init(cfg)
                 elif switch == "setters":
                     T.replay(h, tail)
@@ -79,7 +107,8 @@ def main():
         frames("none", 16)
         r["frame_ms_no_switch"] = round(frames("none"), 4)
         r["frame_ms_switch_device_firmware"] = round(frames("device"), 4)
-        r["frame_ms_switch_host_setters_only"] = round(frames("setters"), 4)   # patterns already made: upload cost only
+        r["frame_ms_same_cfg_resent_every_frame"] = round(frames("same"), 4)   # e.g. AFGS1 with only a new seed per frame
+        r["frame_ms_switch_host_setters_only"] = round(frames("setters"), 4)   # identical state re-sent through the setters (recognised as unchanged)
         # 3. the reference firmware on one host core
         if T.have_reference():
             ref = T.ReferenceHW()

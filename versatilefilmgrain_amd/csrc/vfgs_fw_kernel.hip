@@ -129,6 +129,13 @@ __device__ inline int wave_ror1(int v)
 	return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
 }
 
+__device__ inline int mad24(int a, int b, int c)
+{
+	int d;   // int8 samples x int16 taps: the 24-bit multiply-add is a full-rate instruction
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(c));   // taps are wave-uniform: SGPR operand
+	return d;
+}
+
 template <int L>
 __device__ __forceinline__ void ar_rows(int8_t* buf, const short* coef, int width, int height, int scale, int lane)
 {
@@ -154,22 +161,17 @@ __device__ __forceinline__ void ar_rows(int8_t* buf, const short* coef, int widt
 	const int rnd = 1 << (scale - 1);
 	const int second_at = 64 * K - L;          // lanes 0.. start feeding their second row (y = lane + 64) here
 	const int steps = width + K * (height - 1);
-	auto coords = [&](int t, int& y, int& x) {
-		const int u = t - K * lane;
-		const bool second = u >= second_at;
-		x = second ? u - 64 * K : u;
-		y = second ? lane + 64 : lane;
-	};
-	// operands that are actually used lie inside the buffer; everything else may read any cell
-	const int last = width * height - 1;
-	auto at = [&](int y, int x) { return min(max(y * width + x, 0), last); };
+	// operands that are actually used lie inside the picture buffer; the positions before a row starts
+	// and after it ends read whatever the guard zones around the buffer hold (kArGuardLo / kArGuardHi)
+	auto cell = [&](int i) { return (int)buf[i]; };
 
-	int y, x;
-	coords(0, y, x);
-	int nz = buf[at(y, x)];
+	// per lane: column x of row y; the row's first cell is `row0`
+	int u = -K * lane;                                   // = t - K * lane
+	int x = u, y = lane, row0 = lane * width;
+	int nz = cell(row0 + x);
 	int pre[L];
 #pragma unroll
-	for (int r = 1; r < L; r++) pre[r] = buf[at(y - r - 1, x + L)];
+	for (int r = 1; r < L; r++) pre[r] = cell(row0 - (r + 1) * width + x + L);
 	int out = 0;
 
 	for (int t0 = 0; t0 < steps; t0 += WN)
@@ -177,43 +179,49 @@ __device__ __forceinline__ void ar_rows(int8_t* buf, const short* coef, int widt
 #pragma unroll
 		for (int s = 0; s < WN; s++)
 		{
-			const int t = t0 + s;
-			coords(t, y, x);
+			// next step's position and operands first: they were written long ago (or never: the
+			// noise), so their LDS latency hides behind this step's arithmetic
+			const int un = u + 1;
+			const bool turn = un == second_at && lane + 64 < height;
+			const int xn = turn ? -L : x + 1;
+			const int yn = turn ? lane + 64 : y;
+			const int row0n = turn ? row0 + 64 * width : row0;
+			const int nz_next = cell(row0n + xn);
+			int pre_next[L];
+#pragma unroll
+			for (int r = 1; r < L; r++) pre_next[r] = cell(row0n - (r + 1) * width + xn + L);
+
 			// new right edge of every window (logical position WN-1 lives at physical (WN-1+s) % WN)
 			win[0][(WN - 1 + s) % WN] = wave_ror1(out);
 #pragma unroll
 			for (int r = 1; r < L; r++) win[r][(WN - 1 + s) % WN] = pre[r];
-			// int8 samples x int16 taps: 24-bit multiplies; one accumulator per row keeps the chains short
+			// one accumulator per row keeps the dependent chains short; the tap that needs the DPP result last
 			int acc[L + 1];
 #pragma unroll
-			for (int r = 0; r < L; r++)
+			for (int r = L - 1; r >= 0; r--)
 			{
 				acc[r] = 0;
 #pragma unroll
 				for (int p = 0; p < WN; p++)
-					acc[r] = __mul24(ca[r][p], win[r][(p + s) % WN]) + acc[r];
+					acc[r] = mad24(ca[r][p], win[r][(p + s) % WN], acc[r]);
 			}
 			acc[L] = 0;
 #pragma unroll
-			for (int i = 0; i < L; i++) acc[L] = __mul24(co[i], own[i]) + acc[L];
-			int g = 0;
+			for (int i = L - 1; i >= 0; i--) acc[L] = mad24(co[i], own[i], acc[L]);
+			int g = rnd;
 #pragma unroll
 			for (int r = 0; r <= L; r++) g += acc[r];
-			const bool interior = y >= 3 && y < height && x >= 3 && x < width - 3;   // vfgs_fw.c:470
-			g = interior ? (g + rnd) >> scale : 0;                                   // vfgs_fw.c:488
+			const bool interior = (unsigned)(y - 3) < (unsigned)(height - 3) && (unsigned)(x - 3) < (unsigned)(width - 6);   // vfgs_fw.c:470
+			g = interior ? g >> scale : 0;                                                                            // vfgs_fw.c:488
 			out = clip127(g + nz);
 #pragma unroll
 			for (int i = L - 1; i > 0; i--) own[i] = own[i - 1];
 			own[0] = out;
-			const bool valid = x >= 0 && x < width && y < height;
-			// next step's operands, all written long ago (or never: the noise)
-			int yn, xn;
-			coords(t + 1, yn, xn);
-			const int nz_next = buf[at(yn, xn)];
+			if ((unsigned)x < (unsigned)width && y < height) buf[row0 + x] = (int8_t)out;
+
+			u = un; x = xn; y = yn; row0 = row0n; nz = nz_next;
 #pragma unroll
-			for (int r = 1; r < L; r++) pre[r] = buf[at(yn - r - 1, xn + L)];
-			if (valid) buf[y * width + x] = (int8_t)out;
-			nz = nz_next;
+			for (int r = 1; r < L; r++) pre[r] = pre_next[r];
 			__builtin_amdgcn_wave_barrier();
 		}
 	}
@@ -223,9 +231,13 @@ __global__ __launch_bounds__(256) void fw_ar_kernel(FwLaunch L)
 {
 	const vfgs_hip_pattern_job& jb = L.job[blockIdx.x];
 	if (jb.kind != 1) return;
-	__shared__ int8_t buf[82 * 73 + 2];
+	// reads of not-yet / no-longer needed positions reach at most 3 rows + 3 columns in front of the buffer
+	// and 128 cells behind it
+	constexpr int kArGuardLo = 256, kArGuardHi = 128;
+	__shared__ int8_t arena[kArGuardLo + 82 * 73 + kArGuardHi];
 	__shared__ int8_t G[2048];
 	__shared__ uint32_t W[kFwStreamWords];
+	int8_t* const buf = arena + kArGuardLo;
 	const int tid = threadIdx.x;
 	const int sub = jb.chroma ? 2 : 1;
 	const int width = sub > 1 ? 44 : 82, height = sub > 1 ? 38 : 73;   // vfgs_fw.c:423-424

@@ -268,6 +268,8 @@ struct State {
 	int8_t* dev_raw = nullptr;                // [kSlots][32*32]
 	vfgs::FwConstants* fw_const = nullptr;    // device copy of the model constants + noise streams
 	std::vector<vfgs::FwLaunch> fw_pending;   // generation requests not yet launched (they run on the next grain call's stream)
+	vfgs::FwLaunch fw_last{};                 // the most recent request: re-sending it unchanged (a new seed per frame with the
+	bool fw_last_valid = false;               // same model, the usual AFGS1 stream) generates nothing
 	hipStream_t bank_stream = nullptr;        // stream of the last kernels that touched dev_bank
 	hipEvent_t bank_ev = nullptr;             // ... and their completion, for the (rare) change of stream
 	bool bank_used = false;
@@ -422,6 +424,15 @@ int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
 		L.job[i] = j;
 	}
 	L.njobs = n; L.csubx = s.csubx; L.csuby = s.csuby;   // the layout at the time of the call, as vfgs_hw.c:320-325
+	if (s.fw_last_valid && !memcmp(&L, &s.fw_last, sizeof L))
+	{
+		// identical to the previous request; still current unless a setter replaced one of its slots since
+		bool intact = true;
+		for (int i = 0; i < n; i++) intact = intact && (s.dev_origin[jobs[i].chroma ? 1 : 0] >> jobs[i].index & 1);
+		if (intact) return 0;
+	}
+	s.fw_last = L;
+	s.fw_last_valid = true;
 	if (s.fw_pending.size() >= 64)
 	{   // nobody added grain for 64 configurations: run them now rather than queue without bound
 		if (int e = ensure_init(-1)) return e;
@@ -889,9 +900,12 @@ void vfgs_set_luma_pattern(int index, signed char* P)
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_luma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:316)"); }
-	memcpy(S().bank[0][index], P, 64 * 64);   // vfgs_hw.c:317
-	S().dev_origin[0] &= ~(1u << index);
-	S().tables_dirty = true;
+	State& s = S();
+	const bool host_slot = !(s.dev_origin[0] >> index & 1);
+	if (host_slot && !memcmp(s.bank[0][index], P, 64 * 64)) return;   // unchanged: the device image stays valid
+	memcpy(s.bank[0][index], P, 64 * 64);   // vfgs_hw.c:317
+	s.dev_origin[0] &= ~(1u << index);
+	s.tables_dirty = true;
 }
 
 void vfgs_set_chroma_pattern(int index, signed char* P)
@@ -900,6 +914,10 @@ void vfgs_set_chroma_pattern(int index, signed char* P)
 	S().gen++;
 	State& s = S();
 	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_chroma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:322)"); }
+	bool same = !(s.dev_origin[1] >> index & 1);
+	for (int i = 0; i < 64 / s.csuby && same; i++)
+		same = !memcmp(s.bank[1][index][i], P + (64 / s.csuby) * i, 64 / s.csubx);
+	if (same) return;                        // unchanged: the device image stays valid
 	for (int i = 0; i < 64 / s.csuby; i++)   // vfgs_hw.c:323-324: pitch from csuby, length from csubx
 		memcpy(s.bank[1][index][i], P + (64 / s.csuby) * i, 64 / s.csubx);
 	s.dev_origin[1] &= ~(1u << index);
@@ -911,6 +929,7 @@ void vfgs_set_scale_lut(int c, unsigned char lut[])
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (c < 0 || c > 2) { fail(21, "vfgs_set_scale_lut: component %d", c); die("bad component (vfgs_hw.c:329)"); }
+	if (!memcmp(S().slut[c], lut, 256)) return;   // unchanged (e.g. the same model re-sent with a new seed): nothing to upload
 	memcpy(S().slut[c], lut, 256);
 	S().tables_dirty = true;
 }
@@ -920,6 +939,7 @@ void vfgs_set_pattern_lut(int c, unsigned char lut[])
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (c < 0 || c > 2) { fail(21, "vfgs_set_pattern_lut: component %d", c); die("bad component (vfgs_hw.c:335)"); }
+	if (!memcmp(S().plut[c], lut, 256)) return;
 	memcpy(S().plut[c], lut, 256);
 	S().tables_dirty = true;
 }
@@ -966,6 +986,7 @@ void vfgs_set_chroma_subsampling(int subx, int suby)
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if ((subx != 1 && subx != 2) || (suby != 1 && suby != 2)) { fail(24, "vfgs_set_chroma_subsampling: %d,%d", subx, suby); die("subsampling must be 1 or 2 (vfgs_hw.c:384-385)"); }
+	if (S().csubx == subx && S().csuby == suby) return;
 	S().csubx = subx;
 	S().csuby = suby;
 	S().tables_dirty = true;
@@ -996,6 +1017,7 @@ void vfgs_hip_reset_state(void)
 	memset(s.plut, 0, sizeof s.plut);
 	s.dev_origin[0] = s.dev_origin[1] = 0;
 	s.fw_pending.clear();
+	s.fw_last_valid = false;
 	s.scale_shift = 5 + 6;
 	s.bs = 0;
 	s.ymin = s.cmin = 0;
@@ -1041,6 +1063,7 @@ void vfgs_hip_shutdown(void)
 	s.fw_const = nullptr; s.dev_bank = nullptr; s.dev_raw = nullptr; s.bank_ev = nullptr;
 	s.bank_used = false; s.bank_stream = nullptr;
 	s.dev_origin[0] = s.dev_origin[1] = 0;
+	s.fw_last_valid = false;
 	if (s.own_stream) (void)hipStreamDestroy(s.own_stream);
 	if (s.ev0) (void)hipEventDestroy(s.ev0);
 	if (s.ev1) (void)hipEventDestroy(s.ev1);
