@@ -92,8 +92,10 @@ def cpu_baseline(seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    # the first few dozen launches of a process run 4-8 % slower (clocks / TLBs settling): measured
+    # 376 us per launch at (steps, warmup) = (20, 3), 362 at (50, 5), 348 at (200, 30) and at (1000, 100)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=8, help="frames per launch per rank (a step = gpus*batch frames)")
     ap.add_argument("--pool", type=int, default=4, help="distinct step-sized buffer sets cycled through (total >> 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; cat gpurun_out/bench_default.json
-python bench.py --batch 1 --steps 200 --warmup 20 --pool 24 --no-cpu > gpurun_out/bench_b1.json 2>> gpurun_out/bench_default.err; cat gpurun_out/bench_b1.json
+python bench.py --batch 1 --steps 1000 --warmup 300 --pool 24 --no-cpu > gpurun_out/bench_b1.json 2>> gpurun_out/bench_default.err; cat gpurun_out/bench_b1.json
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/prof_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_fetch.log 2>&1
