@@ -50,13 +50,27 @@ __device__ inline void put_sample(const FwLaunch& L, const vfgs_hip_pattern_job&
 
 // ---------------------------------------------------------------------------------------
 // frequency-filtered pattern: vfgs_fw.c:362-408 (fill) + :297-360 (two basis passes)
+//
+// Both passes are small integer matrix products, X = (D^T B + r) >> s and P = clip((X D + 256) >> 9).
+// The first has int8 operands on both sides -> v_dot4_i32_i8 over four k at a time; the second
+// int16 x int8 -> v_dot2_i32_i16 over two k.  So the operands sit in LDS with k innermost:
+//   Bt[i][k]  = B[k][i]          (noise, written transposed by the fill)        row pitch 68 B
+//   Dt[j][k]  = D[k*dstep][j]    (basis, transposed while loading)              row pitch 68 B
+//   X [j][k]  int16                                                             row pitch 128 B
+//   Dp[k/2][i] = {D[k*dstep][i], D[(k+1)*dstep][i]} as int16x2                  row pitch 256 B
+// A wavefront shares j (its Dt / X reads are broadcasts) and spreads i over the lanes: the
+// 17-dword pitch of Bt and the lane-contiguous Dp make those reads conflict free.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(1024) void fw_ff_kernel(FwLaunch L)
 {
 	const vfgs_hip_pattern_job& jb = L.job[blockIdx.x];
 	if (jb.kind != 0) return;
-	__shared__ int8_t B[64 * 64];
-	__shared__ int16_t X[64 * 64];
-	__shared__ int8_t D[64 * 64];
+	constexpr int BP = 68;                     // Bt / Dt row pitch in bytes
+	__shared__ __attribute__((aligned(16))) int8_t Bt[64 * BP];
+	__shared__ __attribute__((aligned(16))) int8_t Dt[64 * BP];
+	__shared__ __attribute__((aligned(16))) int16_t X[64 * 64];
+	__shared__ __attribute__((aligned(16))) uint32_t Dp[32 * 64];
 	__shared__ int8_t G[2048];
 	__shared__ uint32_t W[40];
 	const int tid = threadIdx.x;
@@ -65,10 +79,24 @@ __global__ __launch_bounds__(1024) void fw_ff_kernel(FwLaunch L)
 	const int gw = N / 16;                   // samples per generator step (vfgs_fw.c:372, :395)
 	const int fh = min(gw * (jb.fh + 1), N); // vfgs_fw.c:366-367, :389-390
 	const int fv = min(gw * (jb.fv + 1), N);
+	const int8_t* D = &L.k->dct[0][0];
 
-	((uint32_t*)D)[tid] = ((const uint32_t*)L.k->dct)[tid];
 	if (tid < 512) ((uint32_t*)G)[tid] = ((const uint32_t*)L.k->gauss)[tid];
 	if (tid < 40) W[tid] = L.k->stream[jb.seed_index][tid];
+	// basis: one (k, j-quad) dword of D per thread -> four bytes of Dt, one (k-pair, i) entry of Dp per thread pair
+	if (tid < N * 16)
+	{
+		const int k = tid >> 4, j4 = (tid & 15) * 4;        // k < N, j4 < 64
+		const uint32_t d = *(const uint32_t*)(D + k * dstep * 64 + j4);
+		for (int q = 0; q < 4; q++)
+			Dt[(j4 + q) * BP + k] = (int8_t)(d >> (8 * q));
+	}
+	for (int o = tid; o < (N / 2) * N; o += 1024)
+	{
+		const int k2 = o / N, i = o % N;
+		const int lo = D[(2 * k2) * dstep * 64 + i], hi = D[(2 * k2 + 1) * dstep * 64 + i];
+		Dp[k2 * 64 + i] = (uint32_t)(uint16_t)(int16_t)lo | ((uint32_t)(uint16_t)(int16_t)hi << 16);
+	}
 	__syncthreads();
 
 	// noise in the low-frequency corner, zero elsewhere; one generator step per group of gw samples
@@ -78,33 +106,33 @@ __global__ __launch_bounds__(1024) void fw_ff_kernel(FwLaunch L)
 		const int r = noise_index(W, tid);
 		const bool in = k < fh && l < fv;
 		for (int j = 0; j < gw; j++)
-			B[l * N + k + j] = (in && (tid || j)) ? G[(r + j) & 2047] : (int8_t)0;   // (tid || j): no DC (vfgs_fw.c:383, :406)
+			Bt[(k + j) * BP + l] = (in && (tid || j)) ? G[(r + j) & 2047] : (int8_t)0;   // (tid || j): no DC (vfgs_fw.c:383, :406)
 	}
 	__syncthreads();
 
-	// Each thread owns column i and rows j0, j0 + step, ... (4 outputs for N = 64, 1 for N = 32),
-	// so one read of B / X serves all of them.
+	// Each thread owns column i and rows j0, j0 + jstep, ... (4 outputs for N = 64, 1 for N = 32).
 	const int i = tid % N, j0 = tid / N, jstep = 1024 / N, per = N * N / 1024;
 	int acc[4];
-	// vertical pass; rows >= fv of B are zero and are skipped
+	// vertical pass: X[j][i] = (r + sum_k D[k][j] B[k][i]) >> s; rows >= fv of B are zero and are skipped
 	for (int m = 0; m < 4; m++) acc[m] = N == 64 ? 256 : 128;   // vfgs_fw.c:307, :340
-	for (int k = 0; k < fv; k++)
+	for (int k4 = 0; k4 < (fv + 3) / 4; k4++)
 	{
-		const int b = B[k * N + i];
+		const int b = *(const int*)(Bt + i * BP + 4 * k4);
 #pragma unroll
 		for (int m = 0; m < 4; m++)
-			if (m < per) acc[m] = __mul24((int)D[k * dstep * 64 + j0 + m * jstep], b) + acc[m];
+			if (m < per) acc[m] = __builtin_amdgcn_sdot4(*(const int*)(Dt + (j0 + m * jstep) * BP + 4 * k4), b, acc[m], false);
 	}
-	for (int m = 0; m < per; m++) X[(j0 + m * jstep) * N + i] = (int16_t)(acc[m] >> (N == 64 ? 9 : 8));
+	for (int m = 0; m < per; m++) X[(j0 + m * jstep) * 64 + i] = (int16_t)(acc[m] >> (N == 64 ? 9 : 8));
 	__syncthreads();
-	// horizontal pass + clip; columns >= fh of X are zero
+	// horizontal pass + clip: P[j][i] = (256 + sum_k X[j][k] D[k][i]) >> 9; columns >= fh of X are zero
 	for (int m = 0; m < 4; m++) acc[m] = 256;                   // vfgs_fw.c:318, :351
-	for (int k = 0; k < fh; k++)
+	for (int k2 = 0; k2 < (fh + 1) / 2; k2++)
 	{
-		const int d = D[k * dstep * 64 + i];
+		const s16x2_t d = __builtin_bit_cast(s16x2_t, Dp[k2 * 64 + i]);
 #pragma unroll
 		for (int m = 0; m < 4; m++)
-			if (m < per) acc[m] = __mul24((int)X[(j0 + m * jstep) * N + k], d) + acc[m];
+			if (m < per)
+				acc[m] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, *(const uint32_t*)(X + (j0 + m * jstep) * 64 + 2 * k2)), d, acc[m], false);
 	}
 	for (int m = 0; m < per; m++) put_sample(L, jb, j0 + m * jstep, i, clip127(acc[m] >> 9));
 }
