@@ -134,6 +134,12 @@ int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV,
 /* {rnd, rnd_up, line_rnd, line_rnd_up} as the reference would hold them (vfgs_hw.c:52-55). */
 void vfgs_hip_get_seed_state(uint32_t out[4]);
 
+/* The rest of the programmed state, for tests and debugging (host only, no GPU needed):
+ * component c's scale and pattern LUTs as vfgs_hw.c:50-51 holds them (either pointer may be NULL), and
+ * out[8] = { scale_shift as stored (vfgs_hw.c:56: shift + 6 - bs), bs, Y min, Y max, C min, C max, csubx, csuby }. */
+int vfgs_hip_get_luts(int c, unsigned char scale[256], unsigned char pattern[256]);
+void vfgs_hip_get_params(int out[8]);
+
 /* Last error of a vfgs_hip_* call (0 = none) and its text. */
 int vfgs_hip_last_error(void);
 const char* vfgs_hip_last_error_string(void);

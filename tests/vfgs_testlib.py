@@ -332,3 +332,27 @@ class BankModel:
     def set_scale_shift(self, s): pass
     def set_depth(self, d): pass
     def set_legal_range(self, l): pass
+
+
+class StateModel(BankModel):
+    """Everything the setters leave behind except the pattern bytes' device copies: banks
+    (BankModel), LUTs, shift (vfgs_hw.c:346-362), ranges (:364-380), subsampling, seed."""
+
+    def __init__(self):
+        super().__init__()
+        self.slut = [bytes(256)] * 3
+        self.plut = [bytes(256)] * 3
+        self.shift, self.bs = 5 + 6, 0
+        self.rng = (0, 255, 0, 255)
+        self.seed = 0xdeadbeef
+
+    def set_scale_lut(self, c, lut): self.slut[c] = bytes(lut)[:256]
+    def set_pattern_lut(self, c, lut): self.plut[c] = bytes(lut)[:256]
+    def set_seed(self, s): self.seed = (s << 1) & 0xFFFFFFFF
+    def set_scale_shift(self, s): self.shift = s + 6 - self.bs
+
+    def set_depth(self, d):
+        self.shift += self.bs - (d - 8)
+        self.bs = d - 8
+
+    def set_legal_range(self, l): self.rng = (16, 235, 16, 240) if l else (0, 255, 0, 255)

@@ -433,12 +433,25 @@ int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
 	}
 	s.fw_last = L;
 	s.fw_last_valid = true;
-	if (s.fw_pending.size() >= 64)
-	{   // nobody added grain for 64 configurations: run them now rather than queue without bound
-		if (int e = ensure_init(-1)) return e;
-		if (int e = fw_flush(s, s.own_stream)) return e;
-	}
 	s.fw_pending.push_back(L);
+	if (s.fw_pending.size() >= 32)
+	{
+		// nobody added grain for many configurations: requests whose every slot is rewritten by a
+		// later request will never be seen -- drop them (at most one request per slot survives)
+		uint32_t covered[2] = {0, 0};
+		std::vector<vfgs::FwLaunch> keep;
+		for (size_t i = s.fw_pending.size(); i-- > 0;)
+		{
+			const vfgs::FwLaunch& q = s.fw_pending[i];
+			bool visible = false;
+			for (int k = 0; k < q.njobs; k++)
+				visible = visible || !(covered[q.job[k].chroma ? 1 : 0] >> q.job[k].index & 1);
+			if (!visible) continue;
+			for (int k = 0; k < q.njobs; k++) covered[q.job[k].chroma ? 1 : 0] |= 1u << q.job[k].index;
+			keep.push_back(q);
+		}
+		s.fw_pending.assign(keep.rbegin(), keep.rend());
+	}
 	for (int i = 0; i < n; i++) s.dev_origin[jobs[i].chroma ? 1 : 0] |= 1u << jobs[i].index;
 	s.tables_dirty = true;
 	return 0;
@@ -1189,6 +1202,23 @@ int vfgs_hip_get_pattern(int chroma, int index, signed char out[64 * 64])
 	else
 		memcpy(out, s.bank[chroma][index], 4096);
 	return 0;
+}
+
+int vfgs_hip_get_luts(int c, unsigned char scale[256], unsigned char pattern[256])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (c < 0 || c > 2) return fail(21, "vfgs_hip_get_luts: component %d", c);
+	if (scale) memcpy(scale, S().slut[c], 256);
+	if (pattern) memcpy(pattern, S().plut[c], 256);
+	return 0;
+}
+
+void vfgs_hip_get_params(int out[8])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	const State& s = S();
+	const int v[8] = {s.scale_shift, s.bs, s.ymin, s.ymax, s.cmin, s.cmax, s.csubx, s.csuby};
+	memcpy(out, v, sizeof v);
 }
 
 int vfgs_hip_last_error(void) { return g_err; }

@@ -51,6 +51,9 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_add_grain_copy8_dev.argtypes = [vp, vp, vp, vp, vp, vp, u, u, u, u, u, u, u, u, u,
                                                  C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     lib.vfgs_hip_get_seed_state.argtypes = [vp]
+    lib.vfgs_hip_get_luts.argtypes = [i, vp, vp]
+    lib.vfgs_hip_get_params.argtypes = [vp]
+    lib.vfgs_hip_get_params.restype = None
     lib.vfgs_hip_last_error_string.restype = C.c_char_p
     lib.vfgs_hip_timer_begin.argtypes = [vp]
     lib.vfgs_hip_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
@@ -68,7 +71,7 @@ EXPORTS = [
     "vfgs_add_grain_stripe", "vfgs_hip_init", "vfgs_hip_shutdown", "vfgs_hip_reset_state",
     "vfgs_hip_add_grain_stripe_dev", "vfgs_hip_add_grain_frame_dev", "vfgs_hip_add_grain_frame_part_dev",
     "vfgs_hip_add_grain_frames_dev", "vfgs_hip_add_grain_frames_part_dev", "vfgs_hip_add_grain_copy_dev",
-    "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_last_error",
+    "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
 ]
 
@@ -144,6 +147,17 @@ class VfgsHip:
         out = (C.c_uint32 * 4)()
         self.lib.vfgs_hip_get_seed_state(out)
         return tuple(out)
+
+    def luts(self, c):
+        """(scale LUT, pattern LUT) of component c as bytes."""
+        a, b = C.create_string_buffer(256), C.create_string_buffer(256)
+        self._ck(self.lib.vfgs_hip_get_luts(c, a, b))
+        return a.raw, b.raw
+
+    def params(self):
+        out = (C.c_int * 8)()
+        self.lib.vfgs_hip_get_params(out)
+        return dict(zip(("scale_shift", "bs", "ymin", "ymax", "cmin", "cmax", "csubx", "csuby"), out))
 
     def device_info(self):
         cu, lds, clk = C.c_int(), C.c_int(), C.c_int()
