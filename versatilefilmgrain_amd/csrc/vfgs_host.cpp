@@ -116,11 +116,26 @@ public:
 			const uint32_t* p = slot_[cur_].host + (w - slot_[cur_].wbase);
 			return sh ? (p[0] >> sh) | (p[1] << (32 - sh)) : p[0];
 		}
+		// outside the window: from a known (word, register) point, 32 words bit by bit, then whole words
+		// by the word recurrence with a 32-word ring (3 ns per 32 steps instead of per step)
 		uint64_t from = 0;
 		uint32_t reg = seed_reg_;
 		if (w >= ck_word_) { from = ck_word_; reg = ck_reg_; }
-		for (uint64_t n = (bit - (from << 5)); n; n--) reg = lfsr_step(reg);
-		return reg;
+		if (w - from < 40)
+		{
+			for (uint64_t n = (bit - (from << 5)); n; n--) reg = lfsr_step(reg);
+			return reg;
+		}
+		uint32_t ring[32];
+		for (int i = 0; i < 32; i++)
+		{
+			ring[i] = reg;
+			for (int k = 0; k < 32; k++) reg = lfsr_step(reg);
+		}
+		for (uint64_t i = from + 32; i <= w + 1; i++)            // word i lives in ring[(i - from) & 31]
+			ring[(i - from) & 31] = ring[(i - from - 31) & 31] ^ ring[(i - from - 3) & 31];
+		const uint32_t lo = ring[(w - from) & 31], hi = ring[(w + 1 - from) & 31];
+		return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
 	}
 
 	// make the device image cover absolute bits [lo, hi + 64); returns 0 or a HIP error
@@ -156,7 +171,19 @@ public:
 			s.host[i] = reg;
 			for (int k = 0; k < 32; k++) reg = lfsr_step(reg);
 		}
-		for (; i < n; i++) s.host[i] = s.host[i - 31] ^ s.host[i - 3];
+		// ... and from word 1024 on by the same recurrence raised to the 32nd power once more,
+		// W[n] = W[n-992] ^ W[n-96]: 96 independent words per step, which the compiler vectorises
+		// (2 MiB of stream: 80 us instead of 1.9 ms -- at 8 frames x 8 stripes per launch the plain
+		// recurrence alone took longer than the kernel it feeds)
+		for (; i < n && i < 1024; i++) s.host[i] = s.host[i - 31] ^ s.host[i - 3];
+		for (; i + 96 <= n; i += 96)
+		{
+			uint32_t* __restrict d = s.host + i;
+			const uint32_t* __restrict a = s.host + i - 992;
+			const uint32_t* __restrict b = s.host + i - 96;
+			for (int k = 0; k < 96; k++) d[k] = a[k] ^ b[k];
+		}
+		for (; i < n; i++) s.host[i] = s.host[i - 992] ^ s.host[i - 96];
 		s.wbase = wlo;
 		s.nwords = n;
 		if ((e = hipMemcpyAsync(s.dev, s.host, n * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
