@@ -438,3 +438,38 @@ def test_fuzz_sizes_formats_and_stripes(hip):
             got = d.download()
         assert got.equal_all(want), (it, name, w, h, pad)
         assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name,seed", [("fgs_sei_10_420", None), ("fgs_afgs1_test1_10_420", 40000)])
+def test_long_stream_across_lfsr_window_refills(hip, name, seed):
+    """240 frames in 20 batched launches: the seed positions walk through ~2.3 Mbit of LFSR stream,
+    i.e. across several refills of the host/device stream window (16 KiB growing to 1 MiB, the
+    blocked word recurrence) -- the last launch and the registers must still equal the oracle, which
+    steps its registers bit by bit through every frame."""
+    import torch
+    from gpu_util import stream_ptr
+    ora, (depth, sx, sy) = program(hip, name)
+    if seed is not None:
+        hip.set_seed(seed)
+        ora.set_seed(seed)
+    per, launches, w, h = 12, 20, 1928, 1088
+    frames, _ = T.lcg_frames(w, h, depth, sx, sy, per)
+    f0 = frames[0]
+    srcY = torch.from_numpy(np.stack([f.Y for f in frames]).view(np.uint8)).cuda()
+    srcU = torch.from_numpy(np.stack([f.U for f in frames]).view(np.uint8)).cuda()
+    srcV = torch.from_numpy(np.stack([f.V for f in frames]).view(np.uint8)).cuda()
+    dY, dU, dV = torch.empty_like(srcY), torch.empty_like(srcU), torch.empty_like(srcV)
+    for _ in range(launches):       # out of place from the same pristine frames every time
+        hip.add_grain_copy_dev(srcY.data_ptr(), srcU.data_ptr(), srcV.data_ptr(), dY.data_ptr(), dU.data_ptr(), dV.data_ptr(),
+                               w, h, 0, h, f0.stride, f0.cstride, per, srcY[0].numel(), srcU[0].numel(), stream_ptr())
+    torch.cuda.synchronize()
+    want = None
+    for _ in range(launches):
+        want = [f.copy() for f in frames]
+        for f in want:
+            ora.add_grain_frame(f)
+    for i, f in enumerate(want):
+        assert np.array_equal(dY[i].cpu().numpy().view(f.dtype).reshape(f.Y.shape), f.Y), i
+        assert np.array_equal(dU[i].cpu().numpy().view(f.dtype).reshape(f.U.shape), f.U), i
+        assert np.array_equal(dV[i].cpu().numpy().view(f.dtype).reshape(f.V.shape), f.V), i
+    assert hip.seed_state() == ora.seed_state()
