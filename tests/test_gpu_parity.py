@@ -458,7 +458,7 @@ def test_long_stream_across_lfsr_window_refills(hip, name, seed):
     srcY = torch.from_numpy(np.stack([f.Y for f in frames]).view(np.uint8)).cuda()
     srcU = torch.from_numpy(np.stack([f.U for f in frames]).view(np.uint8)).cuda()
     srcV = torch.from_numpy(np.stack([f.V for f in frames]).view(np.uint8)).cuda()
-    dY, dU, dV = torch.empty_like(srcY), torch.empty_like(srcU), torch.empty_like(srcV)
+    dY, dU, dV = srcY.clone(), srcU.clone(), srcV.clone()   # (the stride padding beyond the last block is never written)
     for _ in range(launches):       # out of place from the same pristine frames every time
         hip.add_grain_copy_dev(srcY.data_ptr(), srcU.data_ptr(), srcV.data_ptr(), dY.data_ptr(), dU.data_ptr(), dV.data_ptr(),
                                w, h, 0, h, f0.stride, f0.cstride, per, srcY[0].numel(), srcU[0].numel(), stream_ptr())
