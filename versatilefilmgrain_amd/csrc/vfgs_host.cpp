@@ -504,9 +504,11 @@ void build_tables(const State& s, std::vector<uint8_t>& img)
 		{
 			const int slot = s.plut[c][i] >> 4;   // vfgs_hw.c:212
 			const uint32_t sel = slot < vfgs::kSlots ? (uint32_t)slot : 0x0cu;  // slot 8: the reference's all-zero bank
-			const int sc = s.slut[c][i];
-			lut[c * 512 + i] = (sel << 24) | (uint32_t)(uint16_t)(int16_t)sc;          // +scale table
-			lut[c * 512 + 256 + i] = (sel << 24) | (uint32_t)(uint16_t)(int16_t)(-sc); // -scale table
+			// scale pre-shifted so that (scale' * P + 2^15) >> 16 == round(scale * P, scale_shift) (vfgs_hw.c:263):
+			// the kernel reads the result's high half instead of shifting; <= 255 << 10 fits the 24-bit field
+			const int sc = s.slut[c][i] << (16 - s.scale_shift);
+			lut[c * 512 + i] = (sel << 24) | ((uint32_t)sc & 0xffffffu);             // +scale table
+			lut[c * 512 + 256 + i] = (sel << 24) | ((uint32_t)(-sc) & 0xffffffu);    // -scale table
 		}
 }
 
@@ -998,6 +1000,7 @@ void vfgs_set_scale_shift(int shift)
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (shift < 2 || shift >= 8) { fail(22, "vfgs_set_scale_shift: %d", shift); die("shift out of 2..7 (vfgs_hw.c:348)"); }
+	if (S().scale_shift != shift + 6 - S().bs) S().tables_dirty = true;   // the LUT image holds pre-shifted scales
 	S().scale_shift = shift + 6 - S().bs;   // vfgs_hw.c:349
 }
 
@@ -1007,6 +1010,7 @@ void vfgs_set_depth(int depth)
 	S().gen++;
 	State& s = S();
 	if (depth != 8 && depth != 10) { fail(23, "vfgs_set_depth: %d", depth); die("depth must be 8 or 10 (vfgs_hw.c:354)"); }
+	if (s.bs != depth - 8) s.tables_dirty = true;
 	s.scale_shift += s.bs - (depth - 8);     // vfgs_hw.c:356-359
 	s.bs = depth - 8;
 }

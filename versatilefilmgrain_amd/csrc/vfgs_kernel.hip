@@ -110,6 +110,15 @@ __device__ __forceinline__ int mad_i16(int x, uint32_t y, int c)
 	return r;
 }
 
+// x * y.i24 + c: the LUT entry's low 24 bits are the signed scale, pre-shifted so that the product's
+// HIGH half is the scaled grain (see grain_unit); the selector byte above them is ignored by the i24 multiply
+__device__ __forceinline__ int mad_i24(int x, uint32_t y, int c)
+{
+	int r;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(c));
+	return r;
+}
+
 __device__ __forceinline__ int swap_lane_pairs(int v)
 {
 	// quad_perm:[1,0,3,2]: lane 2m <-> lane 2m+1
@@ -320,9 +329,11 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 #pragma unroll
 	for (int k = 0; k < 4; k++)
 	{
-		const int g0 = mad_i16(P[2 * k], e[2 * k], half) >> scale_shift;
-		const int g1 = mad_i16(P[2 * k + 1], e[2 * k + 1], half) >> scale_shift;
-		const uint32_t gp = __builtin_amdgcn_perm((uint32_t)g1, (uint32_t)g0, 0x05040100);
+		// round(scale * P, shift) (vfgs_hw.c:263) = (scale * 2^(16-shift) * P + 2^15) >> 16 exactly; the LUT holds
+		// scale * 2^(16-shift), so the shift is free: the pack below simply takes the high halves
+		const int g0 = mad_i24(P[2 * k], e[2 * k], 0x8000);
+		const int g1 = mad_i24(P[2 * k + 1], e[2 * k + 1], 0x8000);
+		const uint32_t gp = __builtin_amdgcn_perm((uint32_t)g1, (uint32_t)g0, 0x07060302);
 		uint32_t v = w[k];
 		if (DEPTH > 8)  // a 16-bit container may hold anything: keep the add inside int16 (result is clipped anyway)
 			v = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, v), __builtin_bit_cast(u16x2, 0x70007000u)));
