@@ -119,6 +119,14 @@ __device__ __forceinline__ int mad_i24(int x, uint32_t y, int c)
 	return r;
 }
 
+// x * y + c on 24-bit operands, all in VGPRs (or inline constants)
+__device__ __forceinline__ int mad_vvv(int x, int y, int c)
+{
+	int r;
+	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(c));
+	return r;
+}
+
 __device__ __forceinline__ int swap_lane_pairs(int v)
 {
 	// quad_perm:[1,0,3,2]: lane 2m <-> lane 2m+1
@@ -304,16 +312,18 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		Q[6] = pick_slot(c3_.y, c3_.x, e[6]); Q[7] = pick_slot(c3_.w, c3_.z, e[7]);
 #pragma unroll
 		for (int k = 0; k < 8; k++)
-			P[k] = mad24(Q[k], k < 4 ? n0 : n1, mad24(P[k], k < 4 ? m0 : m1, 16)) >> 5;
+			P[k] = mad_vvv(Q[k], k < 4 ? n0 : n1, mad_vvv(P[k], k < 4 ? m0 : m1, 16)) >> 5;
 	}
 
 	// 3-tap filter across the block edge (vfgs_hw.c:250-259), on unfiltered neighbours
+	// (all values are small: explicit 24-bit multiply-adds; the compiler otherwise reaches for 32/64-bit
+	// multiplies and turns the selects into a branch that copies all eight P registers)
 	if (EDGE16)
 	{
 		const int mine = first ? P[0] : P[7];
 		const int inner = first ? P[1] : P[6];
 		const int theirs = swap_lane_pairs(mine);
-		int f = (inner + 3 * mine + __mul24(rel, theirs) + c0) >> 2;
+		int f = mad_vvv(rel, theirs, mad_vvv(3, mine, inner + c0)) >> 2;
 		f = edge_on ? f : mine;
 		P[0] = first ? f : P[0];
 		P[7] = first ? P[7] : f;
@@ -321,8 +331,10 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	else
 	{
 		const int l1 = P[2], l0 = P[3], r0 = P[4], r1 = P[5];
-		P[3] = edge_on ? ((l1 + 3 * l0 + __mul24(rel, r0) + c0) >> 2) : l0;
-		P[4] = edge_on ? ((__mul24(rel, l0) + 3 * r0 + r1 + c1) >> 2) : r0;
+		const int fl = mad_vvv(rel, r0, mad_vvv(3, l0, l1 + c0)) >> 2;
+		const int fr = mad_vvv(rel, l0, mad_vvv(3, r0, r1 + c1)) >> 2;
+		P[3] = edge_on ? fl : l0;
+		P[4] = edge_on ? fr : r0;
 	}
 
 	// scale, add, clip (vfgs_hw.c:263-267)
