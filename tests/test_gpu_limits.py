@@ -108,3 +108,44 @@ def test_narrowest_supported_picture_and_tall_stripe(hip):
     ora.add_grain_frame(want)
     assert d.download().equal_all(want)
     assert hip.seed_state() == ora.seed_state()
+
+
+def test_calls_alternating_between_two_streams(hip):
+    """The library state is one singleton; callers may still spread their launches over streams (and
+    synchronise the FRAMES themselves).  Table and LFSR images uploaded on one stream must be complete
+    before a kernel on the other stream reads them: configuration changes between frames, frames
+    alternate between two streams, every frame is checked."""
+    import torch
+    from gpu_util import DevFrame
+    names = ["fgs_sei_10_420", "fgs_sei_ff_test6_10_420", "fgs_afgs1_test1_10_420", "fgs_sei_ar_test1_10_420"] * 3
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    frames, _ = T.lcg_frames(704, 400, 10, 2, 2, len(names))
+    devs = [DevFrame(f) for f in frames]
+    torch.cuda.synchronize()
+    hip.lib.vfgs_hip_reset_state()
+    ora = T.OracleHW()
+    for i, (name, d, f) in enumerate(zip(names, devs, frames)):
+        rec = T.load_trace(name)
+        T.replay(hip, rec)           # new banks / LUTs / seed before every frame
+        T.replay(ora, rec)
+        st = streams[i & 1]
+        hip.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), f.width, f.height, f.stride, f.cstride, st.cuda_stream)
+        ora.add_grain_frame(f)
+    torch.cuda.synchronize()
+    for i, (d, f) in enumerate(zip(devs, frames)):
+        assert d.download().equal_all(f), i
+    assert hip.seed_state() == ora.seed_state()
+    # and without changes in between: the images uploaded for the first frame (stream 0) are read by the
+    # second frame's kernel on stream 1 -- which has to wait for that upload
+    frames, _ = T.lcg_frames(704, 400, 10, 2, 2, 6, state=99)
+    devs = [DevFrame(f) for f in frames]
+    rec = T.load_trace("fgs_sei_10_420")
+    T.replay(hip, rec)
+    T.replay(ora, rec)
+    torch.cuda.synchronize()
+    for i, (d, f) in enumerate(zip(devs, frames)):
+        hip.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), f.width, f.height, f.stride, f.cstride, streams[i & 1].cuda_stream)
+        ora.add_grain_frame(f)
+    torch.cuda.synchronize()
+    for i, (d, f) in enumerate(zip(devs, frames)):
+        assert d.download().equal_all(f), i

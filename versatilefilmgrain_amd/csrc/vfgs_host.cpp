@@ -294,6 +294,9 @@ struct State {
 	int8_t* dev_bank = nullptr;               // [2][kSlots][64][64]
 	int8_t* dev_raw = nullptr;                // [kSlots][32*32]
 	vfgs::FwConstants* fw_const = nullptr;    // device copy of the model constants + noise streams
+	hipStream_t image_stream = nullptr;       // stream of the most recent table / LFSR image upload
+	hipEvent_t image_ev = nullptr;            // ... recorded behind it, for calls on other streams
+	bool image_uploaded = false;
 	std::vector<vfgs::FwLaunch> fw_pending;   // generation requests not yet launched (they run on the next grain call's stream)
 	vfgs::FwLaunch fw_last{};                 // the most recent request: re-sending it unchanged (a new seed per frame with the
 	bool fw_last_valid = false;               // same model, the usual AFGS1 stream) generates nothing
@@ -699,8 +702,24 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		hi = std::max(hi, p.cur0 + (uint64_t)nbr_stripe * nblk);
 		hi = std::max(hi, p.up0 + nblk);
 	}
-	if (int e = upload_tables(s, stream)) return e;
-	if (int e = upload_stream(s, lo, hi, stream)) return e;
+	// Images are uploaded on the stream of the call that needs them first.  A later call on ANOTHER stream
+	// must not start before that upload: it waits for an event recorded behind the most recent upload.
+	{
+		const void* t0 = s.tables_ring.current();
+		const uint32_t* l0 = s.lfsr.dev();
+		const uint64_t b0 = s.lfsr.base_bit();
+		if (int e = upload_tables(s, stream)) return e;
+		if (int e = upload_stream(s, lo, hi, stream)) return e;
+		if (t0 != s.tables_ring.current() || l0 != s.lfsr.dev() || b0 != s.lfsr.base_bit())
+		{
+			if (!s.image_ev) HIP_TRY(hipEventCreateWithFlags(&s.image_ev, hipEventDisableTiming));
+			HIP_TRY(hipEventRecord(s.image_ev, stream));
+			s.image_stream = stream;
+			s.image_uploaded = true;
+		}
+		else if (s.image_uploaded && stream != s.image_stream)
+			HIP_TRY(hipStreamWaitEvent(stream, s.image_ev, 0));
+	}
 	a.tables = (const uint8_t*)s.tables_ring.current();
 	a.stream = s.lfsr.dev();
 	a.cur_bit0 = (uint32_t)(first_cur - s.lfsr.base_bit());
@@ -1104,6 +1123,8 @@ void vfgs_hip_shutdown(void)
 	if (s.dev_bank) (void)hipFree(s.dev_bank);
 	if (s.dev_raw) (void)hipFree(s.dev_raw);
 	if (s.bank_ev) (void)hipEventDestroy(s.bank_ev);
+	if (s.image_ev) (void)hipEventDestroy(s.image_ev);
+	s.image_ev = nullptr; s.image_uploaded = false; s.image_stream = nullptr;
 	s.fw_const = nullptr; s.dev_bank = nullptr; s.dev_raw = nullptr; s.bank_ev = nullptr;
 	s.bank_used = false; s.bank_stream = nullptr;
 	s.dev_origin[0] = s.dev_origin[1] = 0;
