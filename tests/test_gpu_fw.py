@@ -306,3 +306,44 @@ def test_cfg_file_through_library_equals_reference_cli_md5(hip, corpus, name):
     for f in frames:
         host_frame_call(hip, f)
     assert T.md5_frames(frames) == MD5["small"][name]
+
+
+def test_pattern_jobs_directly_against_the_numpy_restatement(hip):
+    """vfgs_hip_generate_patterns (the extension under the firmware entry points) with random jobs,
+    against oracle/vfgs_fw_oracle.py -- including taps far larger than any real model uses."""
+    import sys
+    sys.path.insert(0, str(T.ROOT / "oracle"))
+    import vfgs_fw_oracle as F
+    from versatilefilmgrain_amd import fw
+    rng = np.random.default_rng(2024)
+    hip.lib.vfgs_hip_reset_state()
+    hip.set_chroma_subsampling(2, 2)
+    for rnd in range(6):
+        jobs, want = [], []
+        for chroma in (0, 1):
+            for slot in rng.permutation(8)[:3]:
+                j = fw.PatternJob()
+                j.chroma, j.index = chroma, int(slot)
+                if rnd % 2 == 0:
+                    j.kind, j.seed_index = 0, int(rng.integers(0, 3))
+                    j.fh, j.fv = int(rng.integers(-1, 17)), int(rng.integers(-1, 17))
+                    want.append(F.ff_pattern(32 if chroma else 64, j.fh, j.fv, j.seed_index))
+                else:
+                    lag = int(rng.integers(1, 4))
+                    big = 2000 if rnd == 5 else 60
+                    taps = np.zeros((4, 7), dtype=np.int64)
+                    for jj in range(-lag, 1):
+                        for ii in range(-lag, lag + 1):
+                            if ii < 0 or jj < 0:
+                                taps[3 + jj, 3 + ii] = int(rng.integers(-big, big + 1))
+                    j.kind, j.seed_index = 1, int(rng.integers(0, 3))
+                    j.scale, j.shift = int(rng.integers(5, 12)), int(rng.integers(1, 5))
+                    for k, v in enumerate(taps.reshape(-1)):
+                        j.coef[k] = int(v)
+                    want.append(F.ar_pattern(bool(chroma), taps, j.scale, j.shift, j.seed_index))
+                jobs.append(j)
+        fw.generate_patterns(jobs)
+        for j, w in zip(jobs, want):
+            n = 32 if j.chroma else 64
+            got = np.frombuffer(fw.get_pattern(j.chroma, j.index), dtype=np.int8).reshape(64, 64)[:n, :n]
+            assert np.array_equal(got, w), (rnd, j.kind, j.chroma, j.index)
