@@ -231,29 +231,47 @@ private:
 
 struct DevRing {
 	static constexpr int N = 4;
-	void* buf[N] = {nullptr, nullptr, nullptr, nullptr};
+	void* buf[N] = {nullptr, nullptr, nullptr, nullptr};      // device images
+	uint8_t* host[N] = {nullptr, nullptr, nullptr, nullptr};  // their pinned host sources (async H2D reads them later)
+	hipEvent_t left[N] = {nullptr, nullptr, nullptr, nullptr}; // recorded when an image is replaced: its readers are done
 	size_t cap[N] = {0, 0, 0, 0};
 	int cur = -1;
 
-	hipError_t next(size_t bytes, void** out)
+	// the next slot, safe to overwrite (host and device side); `stream` is where the replacement is uploaded
+	hipError_t next(size_t bytes, void** dev, uint8_t** src, hipStream_t stream)
 	{
-		cur = (cur + 1) % N;
-		if (cap[cur] < bytes)
-		{
-			if (buf[cur]) (void)hipFree(buf[cur]);
-			buf[cur] = nullptr;
-			cap[cur] = 0;
-			hipError_t e = hipMalloc(&buf[cur], bytes);
-			if (e != hipSuccess) return e;
-			cap[cur] = bytes;
+		hipError_t e;
+		if (cur >= 0)
+		{   // everything queued so far may still read the image we are leaving
+			if (!left[cur] && (e = hipEventCreateWithFlags(&left[cur], hipEventDisableTiming)) != hipSuccess) return e;
+			if ((e = hipEventRecord(left[cur], stream)) != hipSuccess) return e;
 		}
-		*out = buf[cur];
+		const int nxt = (cur + 1) % N;
+		if (left[nxt] && (e = hipEventSynchronize(left[nxt])) != hipSuccess) return e;   // normally long complete
+		if (cap[nxt] < bytes)
+		{
+			if (buf[nxt]) (void)hipFree(buf[nxt]);
+			if (host[nxt]) (void)hipHostFree(host[nxt]);
+			buf[nxt] = nullptr; host[nxt] = nullptr; cap[nxt] = 0;
+			if ((e = hipMalloc(&buf[nxt], bytes)) != hipSuccess) return e;
+			if ((e = hipHostMalloc((void**)&host[nxt], bytes, hipHostMallocDefault)) != hipSuccess) return e;
+			cap[nxt] = bytes;
+		}
+		cur = nxt;
+		*dev = buf[cur];
+		*src = host[cur];
 		return hipSuccess;
 	}
 	void* current() const { return cur < 0 ? nullptr : buf[cur]; }
 	void release()
 	{
-		for (int i = 0; i < N; i++) { if (buf[i]) (void)hipFree(buf[i]); buf[i] = nullptr; cap[i] = 0; }
+		for (int i = 0; i < N; i++)
+		{
+			if (buf[i]) (void)hipFree(buf[i]);
+			if (host[i]) (void)hipHostFree(host[i]);
+			if (left[i]) (void)hipEventDestroy(left[i]);
+			buf[i] = nullptr; host[i] = nullptr; left[i] = nullptr; cap[i] = 0;
+		}
 		cur = -1;
 	}
 };
@@ -281,7 +299,6 @@ struct State {
 	int cu_count = 0;
 	bool tables_dirty = true;
 	DevRing tables_ring;
-	std::vector<uint8_t> tables_host[DevRing::N];
 	// staging for the host-pointer entry points
 	void* stage[3] = {nullptr, nullptr, nullptr};
 	size_t stage_cap[3] = {0, 0, 0};
@@ -489,10 +506,10 @@ int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
 
 // Build the slot-interleaved LDS image of vfgs_layout.h from the mirror.
 template <int CSUBX, int CSUBY>
-void build_tables(const State& s, std::vector<uint8_t>& img)
+void build_tables(const State& s, uint8_t* img)
 {
 	using L = vfgs::TableLayout<CSUBX, CSUBY>;
-	img.assign(L::BYTES, 0);
+	memset(img, 0, L::BYTES);
 	for (int r = 0; r < 64; r++)
 		for (int x = 0; x < 64; x++)
 			for (int k = 0; k < vfgs::kSlots; k++)
@@ -501,7 +518,7 @@ void build_tables(const State& s, std::vector<uint8_t>& img)
 		for (int x = 0; x < L::CW; x++)
 			for (int k = 0; k < vfgs::kSlots; k++)
 				img[L::CHROMA_OFF + r * L::CRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[1][k][r][x];
-	uint32_t* lut = (uint32_t*)(img.data() + L::LUT_OFF);
+	uint32_t* lut = (uint32_t*)(img + L::LUT_OFF);
 	for (int c = 0; c < 3; c++)
 		for (int i = 0; i < 256; i++)
 		{
@@ -532,13 +549,13 @@ int upload_tables(State& s, hipStream_t stream)
 	if (int e = fw_flush(s, stream)) return e;
 	void* dst = nullptr;
 	const int bytes = vfgs::table_bytes(s.csubx, s.csuby);
-	HIP_TRY(s.tables_ring.next(bytes, &dst));
-	std::vector<uint8_t>& img = s.tables_host[s.tables_ring.cur];
+	uint8_t* img = nullptr;
+	HIP_TRY(s.tables_ring.next(bytes, &dst, &img, stream));
 	if (s.csubx == 2 && s.csuby == 2) build_tables<2, 2>(s, img);
 	else if (s.csubx == 2 && s.csuby == 1) build_tables<2, 1>(s, img);
 	else if (s.csubx == 1 && s.csuby == 1) build_tables<1, 1>(s, img);
 	else build_tables<1, 2>(s, img);
-	HIP_TRY(hipMemcpyAsync(dst, img.data(), bytes, hipMemcpyHostToDevice, stream));
+	HIP_TRY(hipMemcpyAsync(dst, img, bytes, hipMemcpyHostToDevice, stream));
 	if (s.dev_origin[0] | s.dev_origin[1])
 	{
 		// device-generated slots never visit the host: copy them bank -> image on the device
