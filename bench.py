@@ -121,7 +121,13 @@ def main():
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # RCCL carries only the barrier and the max over ranks (no collective on the data path); if it
+            # cannot come up on this host the same two calls run over gloo rather than losing the measurement
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            except Exception as e:  # noqa: BLE001
+                print(f"rank {rank}: RCCL unavailable ({e}); using gloo for barrier/max", file=sys.stderr, flush=True)
+                dist.init_process_group("gloo")
 
     h = hw.VfgsHip(device=local)
     T.replay(h, T.load_trace(TRACE))     # programs banks/LUTs/shift/depth/subsampling/seed 12345
@@ -165,7 +171,7 @@ def main():
     barrier()
     launch_ms = ev0.elapsed_time(ev1) / args.steps     # same stream as the kernels (torch's current stream)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
