@@ -1,0 +1,546 @@
+// Developer microbenchmark (not product): which MEMORY STRUCTURE can carry the grain kernel's
+// arithmetic on 4320p 10-bit 4:2:0 at 8 frames per launch?  All kernels move the same bytes
+// (every sample read once, written once, in place unless noted) and run a synthetic VALU + LDS
+// load of configurable size per 16-byte unit, so that the overlap behaviour of each structure
+// shows; results are wrong by design.
+//
+//   flat_copy    out-of-place uint4 copy, grid-stride                       (ceiling A)
+//   flat_rmw     in-place, 4 KiB contiguous per wave step                   (ceiling B)
+//   rowitem      round-1 structure: item = 1 row x 4 segments of one plane, a workgroup takes
+//                consecutive items, load 4 -> compute 4 -> store 4, per-item overhead EXTRA
+//   strip        item rows are walked tile-by-tile down a block row (strip = tile x 8/16 rows);
+//                every wave owns one contiguous range of row items, per-strip overhead EXTRA,
+//                the next row's segment is fetched into the registers just stored (rolling
+//                prefetch, no second register set)
+//
+// hipcc --offload-arch=gfx950 -O3 -o skeleton skeleton.hip && ./skeleton
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <string>
+#include <functional>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOOB = 0x80000000u;
+constexpr int kLdsBytes = 48640;    // the product's table image (4:2:0)
+
+struct Geo {
+	uint8_t* base[3];       // plane pointers of frame 0
+	uint64_t fpitch[3];     // bytes between frames
+	uint32_t extent[3];     // bytes of one frame's plane
+	int pitch[3];           // row pitch, bytes
+	int rows[3];            // rows per frame
+	int rpb[3];             // rows per block row (16 luma, 8 chroma 4:2:0)
+	int tiles[3];           // tiles per row
+	int upt[3];             // lanes used per segment
+	int shift[3];           // bytes the segment grid is shifted left
+	int nframes;
+	int work;               // synthetic compute iterations per segment (8 VALU + 1 LDS gather each)
+	int extra;              // synthetic iterations per item (rowitem) / per strip (strip)
+};
+
+__device__ __forceinline__ void fake_compute(u32x4& v, const uint8_t* lds, int iters, uint32_t salt)
+{
+	uint32_t a = v.x, b = v.y, c = v.z, d = v.w;
+#pragma unroll 4
+	for (int i = 0; i < iters; i++)
+	{
+		const uint32_t t = *(const uint32_t*)(lds + ((a ^ salt) & 0x3ffcu));   // LUT-like gather
+		a = __builtin_amdgcn_perm(a, b, 0x06050403u) + t;
+		b = (b ^ c) + d;
+		c = __builtin_amdgcn_alignbit(c, d, 7) ^ a;
+		d = (d + b) ^ (c >> 3);
+	}
+	v.x = a; v.y = b; v.z = c; v.w = d;
+}
+
+__device__ __forceinline__ void stage_lds(uint8_t* lds, const uint8_t* tables)
+{
+	for (int i = threadIdx.x * 16; i < kLdsBytes; i += blockDim.x * 16)
+		*(u32x4*)(lds + i) = *(const u32x4*)(tables + i);
+	__syncthreads();
+}
+
+__global__ void k_flat_copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n)
+{
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i] + 1u;
+}
+
+template <int UNROLL>
+__global__ void k_flat_rmw(u32x4* __restrict__ buf, size_t n)
+{
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	const int lane = threadIdx.x & 63;
+	for (size_t base = wave * 64 * UNROLL; base + 64 * UNROLL <= n; base += nwaves * 64 * UNROLL)
+	{
+		u32x4 v[UNROLL];
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) v[u] = buf[base + u * 64 + lane];
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) buf[base + u * 64 + lane] = v[u] + 1u;
+	}
+}
+
+// ---- round-1 structure -----------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_rowitem(const Geo g, const uint8_t* tables)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+	stage_lds(lds, tables);
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	int per_plane[3], per_frame = 0;
+	for (int p = 0; p < 3; p++) { per_plane[p] = g.rows[p] * g.tiles[p]; per_frame += per_plane[p]; }
+	const int nitems = per_frame * g.nframes;
+	const int step = gridDim.x * WAVES;
+	for (int item = blockIdx.x * WAVES + wave; item < nitems; item += step)
+	{
+		const int f = item / per_frame;
+		int r = item - f * per_frame, p = 0;
+		while (r >= per_plane[p]) { r -= per_plane[p]; p++; }
+		const int row = r / g.tiles[p], tile = r % g.tiles[p];
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, g.extent[p], 0x00020000);
+		uint32_t off[4];
+		u32x4 v[4];
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			const int x = ((tile * 4 + s) * g.upt[p] + lane) * 16 - g.shift[p];
+			const bool ok = lane < g.upt[p] && x >= 0 && x + 16 <= g.pitch[p];
+			off[s] = ok ? (uint32_t)(row * g.pitch[p] + x) : kOOB;
+			v[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[s], 0, 0);
+		}
+		if (g.extra) { u32x4 t = {off[0], off[1], off[2], off[3]}; fake_compute(t, lds, g.extra, 77u); asm volatile("" :: "v"(t.x), "v"(t.y)); }
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			fake_compute(v[s], lds, g.work, (uint32_t)s);
+			__builtin_amdgcn_raw_buffer_store_b128(v[s], rs, off[s], 0, 0);
+		}
+	}
+}
+
+
+// non-persistent in-place: one 4 KiB chunk per wave, grid covers the buffer
+__global__ void k_flat_rmw_np(u32x4* __restrict__ buf, size_t n)
+{
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int lane = threadIdx.x & 63;
+	const size_t base = wave * 256;
+	if (base + 256 > n) return;
+	u32x4 v[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) v[u] = buf[base + u * 64 + lane];
+#pragma unroll
+	for (int u = 0; u < 4; u++) buf[base + u * 64 + lane] = v[u] + 1u;
+}
+
+// persistent in-place with rolling prefetch: chunk k+1 is requested before chunk k is stored
+template <int UNROLL>
+__global__ void k_flat_rmw_pf(u32x4* __restrict__ buf, size_t n)
+{
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	const int lane = threadIdx.x & 63;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 0, 0x7fffffff, 0x00020000);
+	const size_t nchunks = n / (64 * UNROLL);
+	u32x4 v[UNROLL];
+	size_t c = wave;
+	if (c >= nchunks) return;
+	// chunks beyond 2 GiB: rebase the descriptor per chunk
+	auto desc = [&](size_t chunk) { return __builtin_amdgcn_make_buffer_rsrc((void*)(buf + chunk * 64 * UNROLL), 0, chunk < nchunks ? 1024 * UNROLL : 0, 0x00020000); };
+	__amdgpu_buffer_rsrc_t cur = desc(c);
+#pragma unroll
+	for (int u = 0; u < UNROLL; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(cur, (u * 64 + lane) * 16, 0, 0);
+	for (; c < nchunks; c += nwaves)
+	{
+		const __amdgpu_buffer_rsrc_t nxt = desc(c + nwaves);
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++)
+		{
+			__builtin_amdgcn_raw_buffer_store_b128(v[u] + 1u, cur, (u * 64 + lane) * 16, 0, 0);
+			v[u] = __builtin_amdgcn_raw_buffer_load_b128(nxt, (u * 64 + lane) * 16, 0, 0);
+		}
+		cur = nxt;
+	}
+	(void)rs;
+}
+
+// ---- round-1 item order with rolling prefetch ------------------------------------------------------
+// MODE 0: item = blockIdx * WAVES + wave + k * gridDim * WAVES (round 1);  the next item of a wave is the same
+//         tile `step / tiles` rows further down, so the lane geometry is constant inside a plane
+// MODE 1: every workgroup owns a contiguous range of rows and sweeps it WAVES items (WAVES / tiles rows) at a time
+template <int WAVES, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void k_rowitem_pf(const Geo g, const uint8_t* tables)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+	stage_lds(lds, tables);
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	int per_plane[3], per_frame = 0;
+	for (int p = 0; p < 3; p++) { per_plane[p] = g.rows[p] * g.tiles[p]; per_frame += per_plane[p]; }
+	const long nitems = (long)per_frame * g.nframes;
+	long item, end, step;
+	if (MODE == 0) { item = blockIdx.x * WAVES + wave; end = nitems; step = (long)gridDim.x * WAVES; }
+	else
+	{
+		const long lo = (long)blockIdx.x * nitems / gridDim.x / WAVES * WAVES, hi = blockIdx.x + 1 == gridDim.x ? nitems : (long)(blockIdx.x + 1) * nitems / gridDim.x / WAVES * WAVES;
+		item = lo + wave; end = hi; step = WAVES;
+	}
+	struct It { __amdgpu_buffer_rsrc_t rs; uint32_t off[4]; uint32_t rowb; };
+	auto decode = [&](long it) {
+		It d;
+		const bool valid = it < end;
+		const long i2 = valid ? it : 0;
+		const int f = (int)(i2 / per_frame);
+		int r = (int)(i2 - (long)f * per_frame), p = 0;
+		while (r >= per_plane[p]) { r -= per_plane[p]; p++; }
+		const int row = r / g.tiles[p], tile = r % g.tiles[p];
+		d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, valid ? g.extent[p] : 0, 0x00020000);
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			const int x = ((tile * 4 + s) * g.upt[p] + lane) * 16 - g.shift[p];
+			const bool ok = lane < g.upt[p] && x >= 0 && x + 16 <= g.pitch[p];
+			d.off[s] = ok ? (uint32_t)x : kOOB;
+		}
+		d.rowb = (uint32_t)(row * g.pitch[p]);
+		return d;
+	};
+	if (item >= end) return;
+	It cur = decode(item);
+	u32x4 v[4];
+#pragma unroll
+	for (int s = 0; s < 4; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(cur.rs, cur.off[s], cur.rowb, 0);
+	for (; item < end; item += step)
+	{
+		const It nxt = decode(item + step);
+		if (g.extra) { u32x4 t = {cur.off[0], cur.off[1], cur.off[2], cur.off[3]}; fake_compute(t, lds, g.extra, 77u); asm volatile("" :: "v"(t.x), "v"(t.y)); }
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			u32x4 t = v[s];
+			fake_compute(t, lds, g.work, (uint32_t)s);
+			__builtin_amdgcn_raw_buffer_store_b128(t, cur.rs, cur.off[s], cur.rowb, 0);
+			v[s] = __builtin_amdgcn_raw_buffer_load_b128(nxt.rs, nxt.off[s], nxt.rowb, 0);
+		}
+		cur = nxt;
+	}
+}
+
+
+// ---- round-1 item order, NOT persistent: a workgroup of WAVES waves owns STEPS x WAVES consecutive items and exits;
+// the hardware dispatcher hands out workgroups as CUs free up (dynamic balance, compact in-order window)
+template <int WAVES, int PF>
+__global__ __launch_bounds__(WAVES * 64) void k_rowitem_np(const Geo g, const uint8_t* tables, int steps)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+	stage_lds(lds, tables);
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	int per_plane[3], per_frame = 0;
+	for (int p = 0; p < 3; p++) { per_plane[p] = g.rows[p] * g.tiles[p]; per_frame += per_plane[p]; }
+	const long nitems = (long)per_frame * g.nframes;
+	long item = (long)blockIdx.x * steps * WAVES + wave;
+	const long end = min(nitems, (long)(blockIdx.x + 1) * steps * WAVES);
+	struct It { __amdgpu_buffer_rsrc_t rs; uint32_t off[4]; uint32_t rowb; };
+	auto decode = [&](long it) {
+		It d;
+		const bool valid = it < end;
+		const long i2 = valid ? it : 0;
+		const int f = (int)(i2 / per_frame);
+		int r = (int)(i2 - (long)f * per_frame), p = 0;
+		while (r >= per_plane[p]) { r -= per_plane[p]; p++; }
+		const int row = r / g.tiles[p], tile = r % g.tiles[p];
+		d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, valid ? g.extent[p] : 0, 0x00020000);
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			const int x = ((tile * 4 + s) * g.upt[p] + lane) * 16 - g.shift[p];
+			const bool ok = lane < g.upt[p] && x >= 0 && x + 16 <= g.pitch[p];
+			d.off[s] = ok ? (uint32_t)x : kOOB;
+		}
+		d.rowb = (uint32_t)(row * g.pitch[p]);
+		return d;
+	};
+	if (item >= end) return;
+	It cur = decode(item);
+	u32x4 v[4];
+	if (PF)
+	{
+#pragma unroll
+		for (int s = 0; s < 4; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(cur.rs, cur.off[s], cur.rowb, 0);
+	}
+	for (; item < end; item += WAVES)
+	{
+		const It nxt = decode(item + WAVES);
+		if (!PF)
+		{
+#pragma unroll
+			for (int s = 0; s < 4; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(cur.rs, cur.off[s], cur.rowb, 0);
+		}
+		if (g.extra) { u32x4 t = {cur.off[0], cur.off[1], cur.off[2], cur.off[3]}; fake_compute(t, lds, g.extra, 77u); asm volatile("" :: "v"(t.x), "v"(t.y)); }
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			u32x4 t = v[s];
+			fake_compute(t, lds, g.work, (uint32_t)s);
+			__builtin_amdgcn_raw_buffer_store_b128(t, cur.rs, cur.off[s], cur.rowb, 0);
+			if (PF) v[s] = __builtin_amdgcn_raw_buffer_load_b128(nxt.rs, nxt.off[s], nxt.rowb, 0);
+		}
+		cur = nxt;
+	}
+}
+
+// ---- band order --------------------------------------------------------------------------------
+// A band = one block row of one plane (rpb rows x tiles tiles).  A group of GW waves of a workgroup sweeps a band
+// GW / tiles rows at a time (each step = that many FULL rows, contiguous); wave role inside the group: tile = i % tiles,
+// row phase = i / tiles.  Bands are dealt to groups round-robin.  Per-band overhead EXTRA, rolling prefetch optional.
+template <int WAVES, int GW, int PREFETCH>
+__global__ __launch_bounds__(WAVES * 64) void k_band(const Geo g, const uint8_t* tables)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+	stage_lds(lds, tables);
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int grp = wave / GW, wi = wave % GW, ngrp = gridDim.x * (WAVES / GW);
+	int bands_plane[3], bands_frame = 0;
+	for (int p = 0; p < 3; p++) { bands_plane[p] = (g.rows[p] + g.rpb[p] - 1) / g.rpb[p]; bands_frame += bands_plane[p]; }
+	const int nbands = bands_frame * g.nframes;
+	for (int band = blockIdx.x * (WAVES / GW) + grp; band < nbands; band += ngrp)
+	{
+		const int f = band / bands_frame;
+		int R = band - f * bands_frame, p = 0;
+		while (R >= bands_plane[p]) { R -= bands_plane[p]; p++; }
+		const int tiles = g.tiles[p], phases = GW / tiles;
+		const int tile = wi % tiles, ph = wi / tiles;
+		const int rows_here = min(g.rpb[p], g.rows[p] - R * g.rpb[p]);
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, g.extent[p], 0x00020000);
+		uint32_t off[4];
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			const int x = ((tile * 4 + s) * g.upt[p] + lane) * 16 - g.shift[p];
+			const bool ok = lane < g.upt[p] && x >= 0 && x + 16 <= g.pitch[p];
+			off[s] = ok ? (uint32_t)x : kOOB;
+		}
+		if (g.extra) { u32x4 t = {off[0], off[1], off[2], off[3]}; fake_compute(t, lds, g.extra, 77u); asm volatile("" :: "v"(t.x), "v"(t.y)); }
+		const uint32_t rstep = (uint32_t)(phases * g.pitch[p]);
+		uint32_t rowb = (uint32_t)((R * g.rpb[p] + ph) * g.pitch[p]);
+		u32x4 v[4];
+		if (PREFETCH)
+		{
+			const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, ph < rows_here ? g.extent[p] : 0, 0x00020000);
+#pragma unroll
+			for (int s = 0; s < 4; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(r0, off[s], rowb, 0);
+			for (int j = ph; j < rows_here; j += phases)
+			{
+				const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, j + phases < rows_here ? g.extent[p] : 0, 0x00020000);
+#pragma unroll
+				for (int s = 0; s < 4; s++)
+				{
+					u32x4 t = v[s];
+					fake_compute(t, lds, g.work, (uint32_t)s);
+					__builtin_amdgcn_raw_buffer_store_b128(t, rs, off[s], rowb, 0);
+					v[s] = __builtin_amdgcn_raw_buffer_load_b128(rn, off[s], rowb + rstep, 0);
+				}
+				rowb += rstep;
+			}
+		}
+		else
+		{
+			for (int j = ph; j < rows_here; j += phases)
+			{
+#pragma unroll
+				for (int s = 0; s < 4; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[s], rowb, 0);
+#pragma unroll
+				for (int s = 0; s < 4; s++)
+				{
+					fake_compute(v[s], lds, g.work, (uint32_t)s);
+					__builtin_amdgcn_raw_buffer_store_b128(v[s], rs, off[s], rowb, 0);
+				}
+				rowb += rstep;
+			}
+		}
+	}
+}
+
+// ---- strips with rolling prefetch ----------------------------------------------------------------
+// Row items in the order frame -> plane -> block row -> tile -> row; wave w owns the contiguous
+// range [w * n / nwaves, (w + 1) * n / nwaves).
+template <int WAVES, int PREFETCH>
+__global__ __launch_bounds__(WAVES * 64) void k_strip(const Geo g, const uint8_t* tables)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+	stage_lds(lds, tables);
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	int per_plane[3], per_frame = 0;
+	for (int p = 0; p < 3; p++) { per_plane[p] = g.rows[p] * g.tiles[p]; per_frame += per_plane[p]; }
+	const long nitems = (long)per_frame * g.nframes;
+	const long nw = (long)gridDim.x * WAVES, w = (long)blockIdx.x * WAVES + wave;
+	long item = w * nitems / nw;
+	const long end = (w + 1) * nitems / nw;
+	while (item < end)
+	{
+		// decode the strip that `item` lies in
+		const int f = (int)(item / per_frame);
+		int r = (int)(item - (long)f * per_frame), p = 0;
+		while (r >= per_plane[p]) { r -= per_plane[p]; p++; }
+		const int per_brow = g.rpb[p] * g.tiles[p];
+		const int R = r / per_brow;
+		const int rows_here = min(g.rpb[p], g.rows[p] - R * g.rpb[p]);
+		const int r2 = r - R * per_brow;
+		const int tile = r2 / rows_here, j0 = r2 % rows_here;
+		const int nrows = (int)min((long)(rows_here - j0), end - item);     // rows of this strip that are mine
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, g.extent[p], 0x00020000);
+		uint32_t off[4];
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			const int x = ((tile * 4 + s) * g.upt[p] + lane) * 16 - g.shift[p];
+			const bool ok = lane < g.upt[p] && x >= 0 && x + 16 <= g.pitch[p];
+			off[s] = ok ? (uint32_t)x : kOOB;
+		}
+		if (g.extra) { u32x4 t = {off[0], off[1], off[2], off[3]}; fake_compute(t, lds, g.extra, 77u); asm volatile("" :: "v"(t.x), "v"(t.y)); }
+		uint32_t rowb = (uint32_t)((R * g.rpb[p] + j0) * g.pitch[p]);
+		u32x4 v[4];
+		if (PREFETCH)
+		{
+#pragma unroll
+			for (int s = 0; s < 4; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[s], rowb, 0);
+			for (int j = 0; j < nrows; j++)
+			{
+				// the prefetch of the row after the last one goes through a descriptor with zero records:
+				// the hardware drops it, the instruction stream (and the compiler's vmcnt counting) stays fixed
+				const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, j + 1 < nrows ? g.extent[p] : 0, 0x00020000);
+#pragma unroll
+				for (int s = 0; s < 4; s++)
+				{
+					u32x4 t = v[s];
+					fake_compute(t, lds, g.work, (uint32_t)s);
+					__builtin_amdgcn_raw_buffer_store_b128(t, rs, off[s], rowb, 0);
+					v[s] = __builtin_amdgcn_raw_buffer_load_b128(rn, off[s], rowb + g.pitch[p], 0);
+				}
+				rowb += g.pitch[p];
+			}
+		}
+		else
+		{
+			for (int j = 0; j < nrows; j++)
+			{
+#pragma unroll
+				for (int s = 0; s < 4; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[s], rowb, 0);
+#pragma unroll
+				for (int s = 0; s < 4; s++)
+				{
+					fake_compute(v[s], lds, g.work, (uint32_t)s);
+					__builtin_amdgcn_raw_buffer_store_b128(v[s], rs, off[s], rowb, 0);
+				}
+				rowb += g.pitch[p];
+			}
+		}
+		item += nrows;
+	}
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+int main(int argc, char** argv)
+{
+	const int W = 7680, H = 4320, NF = 8, POOL = 3;
+	const size_t ybytes = (size_t)W * H * 2, cbytes = ybytes / 4, fbytes = ybytes + 2 * cbytes, set = fbytes * NF;
+	uint8_t* pool[POOL];
+	uint8_t* alt;
+	for (int i = 0; i < POOL; i++) { CK(hipMalloc(&pool[i], set)); CK(hipMemset(pool[i], 0x5a + i, set)); }
+	CK(hipMalloc(&alt, set));
+	uint8_t* tables;
+	CK(hipMalloc(&tables, kLdsBytes)); CK(hipMemset(tables, 3, kLdsBytes));
+	hipDeviceProp_t prop;
+	CK(hipGetDeviceProperties(&prop, 0));
+	const int cus = prop.multiProcessorCount;
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+
+	auto geo = [&](int s, int work, int extra) {
+		Geo g{};
+		uint8_t* b = pool[s];
+		g.base[0] = b; g.base[1] = b + ybytes * NF; g.base[2] = b + ybytes * NF + cbytes * NF;
+		g.fpitch[0] = ybytes; g.fpitch[1] = g.fpitch[2] = cbytes;
+		g.extent[0] = (uint32_t)ybytes; g.extent[1] = g.extent[2] = (uint32_t)cbytes;
+		g.pitch[0] = W * 2; g.pitch[1] = g.pitch[2] = W;
+		g.rows[0] = H; g.rows[1] = g.rows[2] = H / 2;
+		g.rpb[0] = 16; g.rpb[1] = g.rpb[2] = 8;
+		g.tiles[0] = 4; g.tiles[1] = g.tiles[2] = 2;
+		g.upt[0] = 62; g.upt[1] = g.upt[2] = 61;
+		g.shift[0] = 16; g.shift[1] = g.shift[2] = 8;
+		g.nframes = NF; g.work = work; g.extra = extra;
+		return g;
+	};
+
+	struct Variant { std::string name; std::function<void(int)> launch; std::vector<float> t; };
+	std::vector<Variant> vs;
+	const size_t n16 = set / 16;
+	vs.push_back({"flat_copy out-of-place 2048x256", [&](int s) { k_flat_copy<<<2048, 256>>>((const u32x4*)pool[s], (u32x4*)alt, n16); }, {}});
+	vs.push_back({"flat_copy out-of-place 4096x256", [&](int s) { k_flat_copy<<<4096, 256>>>((const u32x4*)pool[s], (u32x4*)alt, n16); }, {}});
+	vs.push_back({"flat_rmw x4 in-place 1024x256", [&](int s) { k_flat_rmw<4><<<1024, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw x4 in-place 1536x256", [&](int s) { k_flat_rmw<4><<<1536, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw x4 in-place 2048x256", [&](int s) { k_flat_rmw<4><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw x2 in-place 2048x256", [&](int s) { k_flat_rmw<2><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw x1 in-place 2048x256", [&](int s) { k_flat_rmw<1><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw x4 in-place 3072x256", [&](int s) { k_flat_rmw<4><<<3072, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw x4 in-place 4096x256", [&](int s) { k_flat_rmw<4><<<4096, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw x4 in-place 512x1024", [&](int s) { k_flat_rmw<4><<<512, 1024>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw x8 in-place 2048x256", [&](int s) { k_flat_rmw<8><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw non-persistent x4", [&](int s) { k_flat_rmw_np<<<(unsigned)(n16 / 256 / 4), 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw_pf x4 2048x256", [&](int s) { k_flat_rmw_pf<4><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw_pf x4 1024x256", [&](int s) { k_flat_rmw_pf<4><<<1024, 256>>>((u32x4*)pool[s], n16); }, {}});
+	vs.push_back({"flat_rmw_pf x2 2048x256", [&](int s) { k_flat_rmw_pf<2><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
+	const long nitems_total = (long)(4320 * 4 + 2 * 2160 * 2) * NF;
+	for (int work : {0, 12})
+	{
+		const int extra_item = work ? 36 : 0;
+		char nm[128];
+#define ADD(NAME, ...) snprintf(nm, sizeof nm, NAME " work %d extra %d", work, extra_item); vs.push_back({nm, [&, work, extra_item](int s) { __VA_ARGS__; }, {}})
+#define NPGRID(WAVES, STEPS) (unsigned)((nitems_total + (WAVES) * (STEPS) - 1) / ((WAVES) * (STEPS)))
+		ADD("rowitem 12w x2/CU", k_rowitem<12><<<cus * 2, 768>>>(geo(s, work, extra_item), tables));
+		ADD("rowitem 8w x3/CU", k_rowitem<8><<<cus * 3, 512>>>(geo(s, work, extra_item), tables));
+		ADD("rowitem PF 12w x2/CU", k_rowitem_pf<12, 0><<<cus * 2, 768>>>(geo(s, work, extra_item), tables));
+		ADD("rowitem NP 8w steps 4", k_rowitem_np<8, 0><<<NPGRID(8, 4), 512>>>(geo(s, work, extra_item), tables, 4));
+		ADD("rowitem NP 8w steps 8", k_rowitem_np<8, 0><<<NPGRID(8, 8), 512>>>(geo(s, work, extra_item), tables, 8));
+		ADD("rowitem NP 8w steps 16", k_rowitem_np<8, 0><<<NPGRID(8, 16), 512>>>(geo(s, work, extra_item), tables, 16));
+		ADD("rowitem NP 12w steps 8", k_rowitem_np<12, 0><<<NPGRID(12, 8), 768>>>(geo(s, work, extra_item), tables, 8));
+		ADD("rowitem NP 4w steps 16", k_rowitem_np<4, 0><<<NPGRID(4, 16), 256>>>(geo(s, work, extra_item), tables, 16));
+		ADD("rowitem NP+PF 8w steps 8", k_rowitem_np<8, 1><<<NPGRID(8, 8), 512>>>(geo(s, work, extra_item), tables, 8));
+		ADD("rowitem NP+PF 8w steps 16", k_rowitem_np<8, 1><<<NPGRID(8, 16), 512>>>(geo(s, work, extra_item), tables, 16));
+		ADD("rowitem NP+PF 12w steps 8", k_rowitem_np<12, 1><<<NPGRID(12, 8), 768>>>(geo(s, work, extra_item), tables, 8));
+	}
+
+	const int rounds = argc > 1 ? atoi(argv[1]) : 5, reps = 6;
+	for (int r = 0; r <= rounds; r++)
+		for (auto& v : vs)
+		{
+			CK(hipEventRecord(e0));
+			for (int k = 0; k < reps; k++) v.launch(k % POOL);
+			CK(hipEventRecord(e1));
+			CK(hipEventSynchronize(e1));
+			CK(hipGetLastError());
+			float ms;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			if (r) v.t.push_back(ms / reps * 1e3f);
+		}
+	printf("%-44s %10s %10s %8s %8s\n", "variant (8 frames 4320p 10b 4:2:0 / launch)", "med us", "min us", "GB/s", "of 8TB/s");
+	for (auto& v : vs)
+	{
+		std::sort(v.t.begin(), v.t.end());
+		const float med = v.t[v.t.size() / 2], mn = v.t[0];
+		const double gbs = 2.0 * set / (med * 1e-6) / 1e9;
+		printf("%-44s %10.1f %10.1f %8.0f %8.3f\n", v.name.c_str(), med, mn, gbs, gbs / 8000.0);
+	}
+	return 0;
+}

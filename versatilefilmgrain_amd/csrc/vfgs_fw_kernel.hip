@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void fw_commit_chroma(FwLaunch L)
 // Copy device-generated slots into a table image (TableLayout of vfgs_layout.h) that the host
 // has just uploaded with the host-set slots and the LUTs.
 __global__ __launch_bounds__(256) void fw_patch_tables(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma,
-                                                       int lrs, int chroma_off, int cw, int ch, int crs)
+                                                       int luma_off, int lrs, int chroma_off, int cw, int ch, int crs)
 {
 	const int o = blockIdx.x * 256 + threadIdx.x;
 	if (o < 64 * 64)
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void fw_patch_tables(uint8_t* img, const int8_
 		const int r = o >> 6, x = o & 63;
 		for (int k = 0; k < kSlots; k++)
 			if (mask_luma >> k & 1)
-				img[r * lrs + x * kSlots + k] = (uint8_t)bank[(size_t)k * 4096 + o];
+				img[luma_off + r * lrs + x * kSlots + k] = (uint8_t)bank[(size_t)k * 4096 + o];
 	}
 	else if (o - 4096 < cw * ch)
 	{
@@ -370,7 +370,10 @@ hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma,
 	const int cw = 64 / csubx, ch = 64 / csuby;
 	const int lrs = 64 * kSlots + 16, crs = cw * kSlots + 16;
 	const int n = 4096 + cw * ch;
-	hipLaunchKernelGGL(fw_patch_tables, dim3((n + 255) / 256), dim3(256), 0, stream, img, bank, mask_luma, mask_chroma, lrs, 64 * lrs, cw, ch, crs);
+	// bank offsets in the device image (vfgs_layout.h TableLayout): luma image = [LUT][bank], chroma image = [LUT Cb][LUT Cr][bank]
+	const int lut_bytes = 2 * 256 * 4;
+	const int luma_off = lut_bytes, chroma_off = (lut_bytes + 64 * lrs) + 2 * lut_bytes;
+	hipLaunchKernelGGL(fw_patch_tables, dim3((n + 255) / 256), dim3(256), 0, stream, img, bank, mask_luma, mask_chroma, luma_off, lrs, chroma_off, cw, ch, crs);
 	return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@
 namespace vfgs {
 hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, int grid, hipStream_t stream);
 int table_bytes(int csubx, int csuby);
+void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
 hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby, hipStream_t stream);
 }
@@ -197,6 +198,7 @@ public:
 
 	const uint32_t* dev() const { return cur_ < 0 ? nullptr : slot_[cur_].dev; }
 	uint64_t base_bit() const { return cur_ < 0 ? 0 : slot_[cur_].wbase << 5; }
+	uint64_t dev_words() const { return cur_ < 0 ? 0 : slot_[cur_].nwords; }
 
 	void release()
 	{
@@ -504,22 +506,25 @@ int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
 	return 0;
 }
 
-// Build the slot-interleaved LDS image of vfgs_layout.h from the mirror.
+// Build the device image of vfgs_layout.h (two sub-images: luma LUT + bank, chroma LUTs + bank) from the mirror.
 template <int CSUBX, int CSUBY>
 void build_tables(const State& s, uint8_t* img)
 {
 	using L = vfgs::TableLayout<CSUBX, CSUBY>;
 	memset(img, 0, L::BYTES);
+	uint8_t* yimg = img + L::Y_OFF;
+	uint8_t* cimg = img + L::C_OFF;
 	for (int r = 0; r < 64; r++)
 		for (int x = 0; x < 64; x++)
 			for (int k = 0; k < vfgs::kSlots; k++)
-				img[L::LUMA_OFF + r * L::LRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[0][k][r][x];
+				yimg[L::Y_BANK + r * L::LRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[0][k][r][x];
 	for (int r = 0; r < L::CH; r++)
 		for (int x = 0; x < L::CW; x++)
 			for (int k = 0; k < vfgs::kSlots; k++)
-				img[L::CHROMA_OFF + r * L::CRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[1][k][r][x];
-	uint32_t* lut = (uint32_t*)(img + L::LUT_OFF);
+				cimg[L::C_BANK + r * L::CRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[1][k][r][x];
 	for (int c = 0; c < 3; c++)
+	{
+		uint32_t* lut = (uint32_t*)(c == 0 ? yimg : cimg + (c - 1) * L::LUT_BYTES);
 		for (int i = 0; i < 256; i++)
 		{
 			const int slot = s.plut[c][i] >> 4;   // vfgs_hw.c:212
@@ -527,9 +532,10 @@ void build_tables(const State& s, uint8_t* img)
 			// scale pre-shifted so that (scale' * P + 2^15) >> 16 == round(scale * P, scale_shift) (vfgs_hw.c:263):
 			// the kernel reads the result's high half instead of shifting; <= 255 << 10 fits the 24-bit field
 			const int sc = s.slut[c][i] << (16 - s.scale_shift);
-			lut[c * 512 + i] = (sel << 24) | ((uint32_t)sc & 0xffffffu);             // +scale table
-			lut[c * 512 + 256 + i] = (sel << 24) | ((uint32_t)(-sc) & 0xffffffu);    // -scale table
+			lut[i] = (sel << 24) | ((uint32_t)sc & 0xffffffu);             // +scale table
+			lut[256 + i] = (sel << 24) | ((uint32_t)(-sc) & 0xffffffu);    // -scale table
 		}
+	}
 }
 
 int check_luts(const State& s)
@@ -659,52 +665,47 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	if (yext >= 0x80000000ull || cext >= 0x80000000ull)
 		return fail(15, "a plane stripe of %llu bytes exceeds the 2 GiB buffer window", (unsigned long long)yext);
 	KernelArgs a{};
-	a.Y = (const uint8_t*)sY; a.U = (const uint8_t*)sU; a.V = (const uint8_t*)sV;
-	a.dY = (uint8_t*)dY; a.dU = (uint8_t*)dU; a.dV = (uint8_t*)dV;
-	a.y_extent = (uint32_t)yext; a.c_extent = (uint32_t)cext;
-	a.dy_extent = dg.out8 ? (uint32_t)((uint64_t)part_h * dg.stride) : a.y_extent;
-	a.dc_extent = dg.out8 ? (uint32_t)(crows * dg.cstride) : a.c_extent;
-	a.dy_frame_pitch = dg.out8 ? dg.ypitch : ypitch;
-	a.dc_frame_pitch = dg.out8 ? dg.cpitch : cpitch;
-	a.dstride = dg.out8 ? (int)dg.stride : (int)stride;
-	a.dcstride = dg.out8 ? (int)dg.cstride : (int)cstride;
-	a.y_frame_pitch = ypitch; a.c_frame_pitch = cpitch;
-	a.y0 = (int)part_y; a.nlines = (int)part_h;
+	a.src[0] = (const uint8_t*)sY; a.src[1] = (const uint8_t*)sU; a.src[2] = (const uint8_t*)sV;
+	a.dst[0] = (uint8_t*)dY; a.dst[1] = (uint8_t*)dU; a.dst[2] = (uint8_t*)dV;
+	a.y0 = (int)part_y;
 	a.nblk = (int)nblk;
-	// planes with 16-sample blocks: 2*nblk + 1 units of 8 samples per row incl. the (invalid) one
-	// left of the picture, in the fewest segments of at most 64 units, all of the same even length
-	{
-		const unsigned tunits = 2 * nblk + 1;
-		a.segs_y = (int)((tunits + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits);
-		a.upt_y = (int)(2 * ((tunits + 2 * a.segs_y - 1) / (2 * a.segs_y)));
-#ifdef VFGS_FULL_SEGMENTS          // tools/ablate.py knob: 1 KiB segments, the last one mostly empty (measured: no difference)
-		a.upt_y = vfgs::kMaxUnits;
-#endif
-		a.tiles_y = (a.segs_y + 3) / 4;
-		if (s.csubx == 2)
-		{   // 8-sample chroma blocks: one lane per block edge m = 0 .. nblk
-			const unsigned tedges = nblk + 1;
-			a.segs_c = (int)((tedges + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits);
-			a.upt_c = (int)((tedges + a.segs_c - 1) / a.segs_c);
-#ifdef VFGS_FULL_SEGMENTS
-			a.upt_c = vfgs::kMaxUnits;
-#endif
-			a.tiles_c = (a.segs_c + 3) / 4;
-		}
-		else { a.segs_c = a.segs_y; a.upt_c = a.upt_y; a.tiles_c = a.tiles_y; }
-		a.crow_first = (int)((part_y + s.csuby - 1) / s.csuby);
-		a.ncrows = (int)((part_y + part_h + s.csuby - 1) / s.csuby) - a.crow_first;
-		a.items_y = (int)part_h * a.tiles_y;
-		a.items_c = a.ncrows * a.tiles_c;
-		a.lut_off = (uint32_t)(vfgs::table_bytes(s.csubx, s.csuby) - 3 * 2 * 256 * 4);
-		a.chroma_off = 64u * (64 * vfgs::kSlots + 16);
-	}
 	const int nbr_stripe = (int)(((part_y + part_h - 1) >> 4) - (part_y >> 4) + 1);
-	a.stride = (int)stride; a.cstride = (int)cstride;
+	a.nbrows = nbr_stripe;
 	a.nframes = (int)nframes;
-	a.scale_shift = s.scale_shift;
-	a.ylo = s.ymin << s.bs; a.yhi = s.ymax << s.bs;
-	a.clo = s.cmin << s.bs; a.chi = s.cmax << s.bs;
+	a.lo2[0] = (uint32_t)(s.ymin << s.bs) * 0x10001u; a.hi2[0] = (uint32_t)(s.ymax << s.bs) * 0x10001u;
+	a.lo2[1] = (uint32_t)(s.cmin << s.bs) * 0x10001u; a.hi2[1] = (uint32_t)(s.cmax << s.bs) * 0x10001u;
+	for (int pt = 0; pt < 2; pt++)
+	{
+		// geometry of the plane type: lanes of 16 bytes, segments of <= 64 lanes, tiles of 4 segments, and the
+		// shape of a workgroup (vfgs_layout.h PlaneDesc, vfgs_kernel.hip "Lanes")
+		vfgs::PlaneDesc& d = a.pd[pt];
+		const unsigned subx = pt ? s.csubx : 1, suby = pt ? s.csuby : 1;
+		const unsigned bw = 16 / subx, rpb = 16 / suby;
+		d.pitch = (pt ? cstride : stride) * sz;
+		d.dpitch = dg.out8 ? (pt ? dg.cstride : dg.stride) : d.pitch;
+		d.extent = (uint32_t)(pt ? cext : yext);
+		d.dextent = dg.out8 ? (uint32_t)(pt ? crows * dg.cstride : (uint64_t)part_h * dg.stride) : d.extent;
+		d.fpitch = pt ? cpitch : ypitch;
+		d.dfpitch = dg.out8 ? (pt ? dg.cpitch : dg.ypitch) : d.fpitch;
+		d.rowbytes = nblk * bw * sz;
+		d.drowbytes = dg.out8 ? nblk * bw : d.rowbytes;
+		d.nrows = pt ? (int)((part_y + part_h + suby - 1) / suby) - (int)((part_y + suby - 1) / suby) : (int)part_h;
+		int shift_samples = 0, lanes = 0;
+		vfgs::lane_layout(8 + s.bs, (int)bw, (int)nblk, &shift_samples, &lanes);
+		d.segs = (lanes + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
+		d.upt = (lanes + d.segs - 1) / d.segs;
+		if (d.upt & 1) d.upt++;                     // even: the lanes of a pair (and their roles) stay together in every segment
+		d.tiles = (d.segs + vfgs::kSegsPerTile - 1) / vfgs::kSegsPerTile;
+		d.tiles_w = 1;
+		while (d.tiles_w < d.tiles && d.tiles_w < vfgs::kWavesPerWG) d.tiles_w *= 2;
+		d.colgroups = (d.tiles + d.tiles_w - 1) / d.tiles_w;
+		const int phases = vfgs::kWavesPerWG / d.tiles_w;
+		d.ppb = std::min<int>(phases, std::max<int>(1, (int)rpb / vfgs::kRowsPerWave));
+		d.bpw = phases / d.ppb;
+		d.splits = std::max<int>(1, (int)rpb / (d.ppb * vfgs::kRowsPerWave));
+		const int nbgroups = (nbr_stripe + d.bpw - 1) / d.bpw;
+		d.wgs = d.nrows > 0 ? nbgroups * d.splits * d.colgroups : 0;
+	}
 
 	// seeds: every frame of the batch runs the full state machine; frame 0's part gives the offsets
 	uint64_t first_cur = 0, first_up = 0, second_cur = 0, lo = ~0ull, hi = 0;
@@ -739,16 +740,16 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	}
 	a.tables = (const uint8_t*)s.tables_ring.current();
 	a.stream = s.lfsr.dev();
+	a.stream_bytes = (uint32_t)(s.lfsr.dev_words() * 4);
 	a.cur_bit0 = (uint32_t)(first_cur - s.lfsr.base_bit());
 	a.up_bit0 = (uint32_t)(first_up - s.lfsr.base_bit());
 	a.frame_bit_step = nframes > 1 ? (uint32_t)(second_cur - first_cur) : 0;
 
-	const long total = ((long)a.items_y + 2L * a.items_c) * a.nframes;
+	// one workgroup per (plane, group of rows, group of tiles), numbered in memory order; not persistent
+	const long total = ((long)a.pd[0].wgs + 2L * a.pd[1].wgs) * a.nframes;
 	if (total > 0x7fffffffL) return fail(14, "launch too large");
-	a.nitems = (int)total;
-	// persistent workgroups: at most kWGPerCU per CU, each loops over the items round-robin
-	const int grid = (int)std::min<long>((total + vfgs::kWavesPerWG - 1) / vfgs::kWavesPerWG, (long)s.cu_count * vfgs::kWGPerCU);
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, grid, stream));
+	if (total == 0) return 0;
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, (int)total, stream));
 	return 0;
 }
 
