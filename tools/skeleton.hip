@@ -297,6 +297,84 @@ __global__ __launch_bounds__(WAVES * 64) void k_rowitem_np(const Geo g, const ui
 	}
 }
 
+
+// ---- round-1 item order, persistent workgroups that draw chunks of STEPS x WAVES consecutive items from ONE device
+// counter (dynamic balance, compact in-order window, no dispatch / staging dead time); the ticket for the chunk after
+// next is drawn while the current one is processed, the rolling prefetch runs across chunk boundaries
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_rowitem_dyn(const Geo g, const uint8_t* tables, int steps, unsigned* counter)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+	__shared__ unsigned s_ticket[2];
+	stage_lds(lds, tables);
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	int per_plane[3], per_frame = 0;
+	for (int p = 0; p < 3; p++) { per_plane[p] = g.rows[p] * g.tiles[p]; per_frame += per_plane[p]; }
+	const long nitems = (long)per_frame * g.nframes;
+	const unsigned chunk = steps * WAVES;
+	const unsigned nchunks = (unsigned)((nitems + chunk - 1) / chunk);
+	struct It { __amdgpu_buffer_rsrc_t rs; uint32_t off[4]; uint32_t rowb; };
+	auto decode = [&](long it, bool valid) {
+		It d;
+		valid = valid && it < nitems;
+		const long i2 = valid ? it : 0;
+		const int f = (int)(i2 / per_frame);
+		int r = (int)(i2 - (long)f * per_frame), p = 0;
+		while (r >= per_plane[p]) { r -= per_plane[p]; p++; }
+		const int row = r / g.tiles[p], tile = r % g.tiles[p];
+		d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.base[p] + (uint64_t)f * g.fpitch[p]), 0, valid ? g.extent[p] : 0, 0x00020000);
+#pragma unroll
+		for (int s = 0; s < 4; s++)
+		{
+			const int x = ((tile * 4 + s) * g.upt[p] + lane) * 16 - g.shift[p];
+			const bool ok = lane < g.upt[p] && x >= 0 && x + 16 <= g.pitch[p];
+			d.off[s] = ok ? (uint32_t)x : kOOB;
+		}
+		d.rowb = (uint32_t)(row * g.pitch[p]);
+		return d;
+	};
+	// tickets: cur = chunk being processed, nxt = the one after it (already drawn)
+	if (threadIdx.x == 0) { s_ticket[0] = atomicAdd(counter, 1u); s_ticket[1] = atomicAdd(counter, 1u); }
+	__syncthreads();
+	unsigned cur = s_ticket[0], nxt = s_ticket[1];
+	__syncthreads();
+	if (cur >= nchunks) return;
+	It ci = decode((long)cur * chunk + wave, true);
+	u32x4 v[4];
+#pragma unroll
+	for (int s = 0; s < 4; s++) v[s] = __builtin_amdgcn_raw_buffer_load_b128(ci.rs, ci.off[s], ci.rowb, 0);
+	while (cur < nchunks)
+	{
+		// the chunk after next; consumed at the end of this chunk.  Branch-free (one lane has a valid offset): a branch
+		// around a vector-memory instruction would make the compiler wait for ALL outstanding loads at every wait
+		const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)counter, 0, 4, 0x00020000);
+		const unsigned drawn = (unsigned)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, crs, threadIdx.x == 0 ? 0u : kOOB, 0, 0);
+		for (int st = 0; st < steps; st++)
+		{
+			const bool lastst = st + 1 == steps;
+			const long nit = lastst ? (long)nxt * chunk + wave : (long)cur * chunk + (st + 1) * WAVES + wave;
+			const It ni = decode(nit, !lastst || nxt < nchunks);
+			if (g.extra) { u32x4 t = {ci.off[0], ci.off[1], ci.off[2], ci.off[3]}; fake_compute(t, lds, g.extra, 77u); asm volatile("" :: "v"(t.x), "v"(t.y)); }
+#pragma unroll
+			for (int s = 0; s < 4; s++)
+			{
+				u32x4 t = v[s];
+				fake_compute(t, lds, g.work, (uint32_t)s);
+				__builtin_amdgcn_raw_buffer_store_b128(t, ci.rs, ci.off[s], ci.rowb, 0);
+				v[s] = __builtin_amdgcn_raw_buffer_load_b128(ni.rs, ni.off[s], ni.rowb, 0);
+			}
+			ci = ni;
+		}
+		if (threadIdx.x == 0) s_ticket[0] = drawn;
+		__builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0) only
+		__builtin_amdgcn_s_barrier();
+		cur = nxt;
+		nxt = s_ticket[0];
+		__builtin_amdgcn_s_barrier();
+	}
+}
+
 // ---- band order --------------------------------------------------------------------------------
 // A band = one block row of one plane (rpb rows x tiles tiles).  A group of GW waves of a workgroup sweeps a band
 // GW / tiles rows at a time (each step = that many FULL rows, contiguous); wave role inside the group: tile = i % tiles,
@@ -502,6 +580,8 @@ int main(int argc, char** argv)
 	vs.push_back({"flat_rmw_pf x4 1024x256", [&](int s) { k_flat_rmw_pf<4><<<1024, 256>>>((u32x4*)pool[s], n16); }, {}});
 	vs.push_back({"flat_rmw_pf x2 2048x256", [&](int s) { k_flat_rmw_pf<2><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
 	const long nitems_total = (long)(4320 * 4 + 2 * 2160 * 2) * NF;
+	unsigned* counter;
+	CK(hipMalloc(&counter, 4));
 	for (int work : {0, 12})
 	{
 		const int extra_item = work ? 36 : 0;
@@ -509,16 +589,17 @@ int main(int argc, char** argv)
 #define ADD(NAME, ...) snprintf(nm, sizeof nm, NAME " work %d extra %d", work, extra_item); vs.push_back({nm, [&, work, extra_item](int s) { __VA_ARGS__; }, {}})
 #define NPGRID(WAVES, STEPS) (unsigned)((nitems_total + (WAVES) * (STEPS) - 1) / ((WAVES) * (STEPS)))
 		ADD("rowitem 12w x2/CU", k_rowitem<12><<<cus * 2, 768>>>(geo(s, work, extra_item), tables));
-		ADD("rowitem 8w x3/CU", k_rowitem<8><<<cus * 3, 512>>>(geo(s, work, extra_item), tables));
-		ADD("rowitem PF 12w x2/CU", k_rowitem_pf<12, 0><<<cus * 2, 768>>>(geo(s, work, extra_item), tables));
 		ADD("rowitem NP 8w steps 4", k_rowitem_np<8, 0><<<NPGRID(8, 4), 512>>>(geo(s, work, extra_item), tables, 4));
-		ADD("rowitem NP 8w steps 8", k_rowitem_np<8, 0><<<NPGRID(8, 8), 512>>>(geo(s, work, extra_item), tables, 8));
-		ADD("rowitem NP 8w steps 16", k_rowitem_np<8, 0><<<NPGRID(8, 16), 512>>>(geo(s, work, extra_item), tables, 16));
-		ADD("rowitem NP 12w steps 8", k_rowitem_np<12, 0><<<NPGRID(12, 8), 768>>>(geo(s, work, extra_item), tables, 8));
-		ADD("rowitem NP 4w steps 16", k_rowitem_np<4, 0><<<NPGRID(4, 16), 256>>>(geo(s, work, extra_item), tables, 16));
-		ADD("rowitem NP+PF 8w steps 8", k_rowitem_np<8, 1><<<NPGRID(8, 8), 512>>>(geo(s, work, extra_item), tables, 8));
-		ADD("rowitem NP+PF 8w steps 16", k_rowitem_np<8, 1><<<NPGRID(8, 16), 512>>>(geo(s, work, extra_item), tables, 16));
-		ADD("rowitem NP+PF 12w steps 8", k_rowitem_np<12, 1><<<NPGRID(12, 8), 768>>>(geo(s, work, extra_item), tables, 8));
+		ADD("rowitem NP+PF 8w steps 4", k_rowitem_np<8, 1><<<NPGRID(8, 4), 512>>>(geo(s, work, extra_item), tables, 4));
+		ADD("rowitem NP+PF 4w steps 4", k_rowitem_np<4, 1><<<NPGRID(4, 4), 256>>>(geo(s, work, extra_item), tables, 4));
+		ADD("rowitem DYN 8w x3/CU steps 4", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<8><<<cus * 3, 512>>>(geo(s, work, extra_item), tables, 4, counter));
+		ADD("rowitem DYN 8w x3/CU steps 2", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<8><<<cus * 3, 512>>>(geo(s, work, extra_item), tables, 2, counter));
+		ADD("rowitem DYN 8w x3/CU steps 1", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<8><<<cus * 3, 512>>>(geo(s, work, extra_item), tables, 1, counter));
+		ADD("rowitem DYN 4w x4/CU steps 4", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<4><<<cus * 4, 256>>>(geo(s, work, extra_item), tables, 4, counter));
+		ADD("rowitem DYN 4w x4/CU steps 2", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<4><<<cus * 4, 256>>>(geo(s, work, extra_item), tables, 2, counter));
+		ADD("rowitem DYN 4w x6/CU steps 4", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<4><<<cus * 6, 256>>>(geo(s, work, extra_item), tables, 4, counter));
+		ADD("rowitem DYN 12w x2/CU steps 2", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<12><<<cus * 2, 768>>>(geo(s, work, extra_item), tables, 2, counter));
+		ADD("rowitem DYN 16w x2/CU steps 1", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<16><<<cus * 2, 1024>>>(geo(s, work, extra_item), tables, 1, counter));
 	}
 
 	const int rounds = argc > 1 ? atoi(argv[1]) : 5, reps = 6;

@@ -8,13 +8,17 @@ namespace vfgs {
 constexpr int kSlots = 8;        // pattern slots per component, vfgs_hw.h:49
 constexpr int kMaxUnits = 64;    // 16-byte units per segment (one per lane)
 constexpr int kSegsPerTile = 4;  // segments a wave moves per row
-constexpr int kWavesPerWG = 8;   // waves per workgroup; they share one LDS image
-constexpr int kRowsPerWave = 4;  // rows of one tile a wave walks (block parameters are computed once for them)
 constexpr int kBlock = 16;       // luma samples per grain block
 
 // Tuning knobs (defaults are the shipped configuration; tools/ablate.py overrides them).
+#ifndef VFGS_WAVES
+#define VFGS_WAVES 4          // waves per workgroup (power of two); they share one LDS image
+#endif
+#ifndef VFGS_ROWS_PER_WAVE
+#define VFGS_ROWS_PER_WAVE 4  // rows of one tile a wave walks (block parameters are computed once for them): 1, 2, 4, 8
+#endif
 #ifndef VFGS_WG_PER_CU
-#define VFGS_WG_PER_CU 3  // resident workgroups per CU the register allocation is sized for
+#define VFGS_WG_PER_CU 4  // resident workgroups per CU the register allocation is sized for
 #endif
 #ifndef VFGS_LDAUX
 #define VFGS_LDAUX 0      // cache policy bits of the sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
@@ -30,6 +34,9 @@ constexpr int kBlock = 16;       // luma samples per grain block
                           //   1 copy only (tables still staged, block parameters still computed), 2 copy only + no staging,
                           //   5 no stores, 8 no LUT gather, 9 no pattern fetch
 #endif
+
+constexpr int kWavesPerWG = VFGS_WAVES;
+constexpr int kRowsPerWave = VFGS_ROWS_PER_WAVE;
 
 // Device image of everything the kernel looks up: two sub-images, one per plane type; a workgroup
 // (which works on ONE plane) copies the sub-image of its plane type to LDS offset 0.
