@@ -192,7 +192,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	constexpr int NS = DEPTH == 8 ? 16 : 8;
 	using M = LaneMap<NS, BW>;
 	constexpr int NR = M::NR, NQ = M::NQ;
-#if VFGS_ABLATE == 1 || VFGS_ABLATE == 2
+#if VFGS_ABLATE >= 1 && VFGS_ABLATE <= 4
 	return;
 #endif
 	// unpack the block parameters
@@ -387,7 +387,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	constexpr int NR = M::NR;
 	constexpr int RPB = 16 / SUBY;                       // rows of this plane per block row
 	constexpr int NEF = M::PAIR ? 1 : M::NE;
-	constexpr bool PARTIAL = !M::PAIR;                   // rows of this plane type begin and end with a partly valid lane
+	constexpr bool PARTIAL = !M::PAIR && VFGS_ABLATE != 4;   // rows of this plane type begin and end with a partly valid lane
 	constexpr bool HALVES = !(NS == 16 && BW == 8);      // ... whose valid part is one 8-byte half (else: 1 or 3 dwords)
 	const int pt = comp ? 1 : 0;
 
@@ -519,8 +519,12 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 #pragma unroll
 		for (int rr = 0; rr < NR; rr++)
 		{
+#if VFGS_ABLATE == 3
+			wcur[g][rr] = u32x2{(uint32_t)blk[g][rr], 7u}; wup[g][rr] = wcur[g][rr];
+#else
 			wcur[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs, ((cur_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
 			if (any_up) wup[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs, ((up_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
+#endif
 		}
 	uint32_t rowb = (uint32_t)uni((base + pd.ppb * k0 - prow0) * (int)pd.pitch), drowb = (uint32_t)uni((base + pd.ppb * k0 - prow0) * (int)pd.dpitch);
 	const uint32_t rstep = (uint32_t)pd.ppb * pd.pitch, drstep = (uint32_t)pd.ppb * pd.dpitch;

@@ -32,6 +32,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_ABLATE
 #define VFGS_ABLATE 0     // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py):
                           //   1 copy only (tables still staged, block parameters still computed), 2 copy only + no staging,
+                          //   3 copy only + no LFSR loads, 4 copy only + partly valid lanes ignored,
                           //   5 no stores, 8 no LUT gather, 9 no pattern fetch
 #endif
 
