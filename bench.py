@@ -89,18 +89,25 @@ def cpu_baseline(seconds=10.0):
             "host_cpus": os.cpu_count()}
 
 
+def kernel_sha():
+    import hashlib
+    return hashlib.sha256((ROOT / "versatilefilmgrain_amd" / "csrc" / "vfgs_kernel.hip").read_bytes()).hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # the first few dozen launches of a process run 4-8 % slower (clocks / TLBs settling): measured
-    # 376 us per launch at (steps, warmup) = (20, 3), 362 at (50, 5), 348 at (200, 30) and at (1000, 100)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=8, help="frames per launch per rank (a step = gpus*batch frames)")
     ap.add_argument("--pool", type=int, default=4, help="distinct step-sized buffer sets cycled through (total >> 256 MiB Infinity Cache)")
+    # the first ~10 ms of launches of a process run 4-8 % slower (clocks / TLBs settling); an untimed, time-based
+    # pre-roll in front of --warmup makes the line independent of how few --steps/--warmup the caller asks for
+    ap.add_argument("--preroll-ms", type=float, default=150.0, help="untimed launches for at least this long before --warmup")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the same-process copy ceiling")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="developer option: run the N-rank code path with all ranks on cuda:0 and gloo instead of RCCL")
+                    help="developer option: run the N-rank code path with all ranks on cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -117,17 +124,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            # RCCL carries only the barrier and the max over ranks (no collective on the data path); if it
-            # cannot come up on this host the same two calls run over gloo rather than losing the measurement
-            try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            except Exception as e:  # noqa: BLE001
-                print(f"rank {rank}: RCCL unavailable ({e}); using gloo for barrier/max", file=sys.stderr, flush=True)
-                dist.init_process_group("gloo")
+        # The data path has no collective (stripes are independent, DESIGN.md "multi-GPU"): the process group only
+        # carries the barrier around the timed region and the max / gather of the timings -- host-side, over gloo.
+        dist.init_process_group("gloo")
 
     h = hw.VfgsHip(device=local)
     T.replay(h, T.load_trace(TRACE))     # programs banks/LUTs/shift/depth/subsampling/seed 12345
@@ -141,20 +140,31 @@ def main():
     cpitch = (part_h // SUBY) * cstride * 2
     pool = max(2, min(args.pool, args.steps + args.warmup))
     g = torch.Generator(device="cuda").manual_seed(1 + rank)
-    Y = torch.randint(0, 1024, (pool, frames_per_launch, part_h, stride), dtype=torch.int16, device="cuda", generator=g)
-    U = torch.randint(0, 1024, (pool, frames_per_launch, part_h // SUBY, cstride), dtype=torch.int16, device="cuda", generator=g)
-    V = torch.randint(0, 1024, (pool, frames_per_launch, part_h // SUBY, cstride), dtype=torch.int16, device="cuda", generator=g)
+    # one allocation per buffer set: [Y stripes of all frames | U | V], so that the copy-ceiling kernels can stream
+    # exactly the bytes of a grain launch in ONE launch of their own
+    ny, nc = frames_per_launch * part_h * stride, frames_per_launch * (part_h // SUBY) * cstride
+    sets = [torch.randint(0, 1024, (ny + 2 * nc,), dtype=torch.int16, device="cuda", generator=g) for _ in range(pool)]
+    set_bytes = (ny + 2 * nc) * 2
+    ptrs = [(b.data_ptr(), b.data_ptr() + 2 * ny, b.data_ptr() + 2 * (ny + nc)) for b in sets]
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
-        s = i % pool
-        h.add_grain_frames_part_dev(Y[s].data_ptr(), U[s].data_ptr(), V[s].data_ptr(), W, H, part_y, part_h,
-                                    stride, cstride, frames_per_launch, ypitch, cpitch, stream)
+        y, u, v = ptrs[i % pool]
+        h.add_grain_frames_part_dev(y, u, v, W, H, part_y, part_h, stride, cstride, frames_per_launch, ypitch, cpitch, stream)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    # untimed pre-roll (time based), then the contract's warmup
+    t0 = time.perf_counter()
+    n_pre = 0
+    while (time.perf_counter() - t0) * 1e3 < args.preroll_ms:
+        for _ in range(8):
+            step(n_pre)
+            n_pre += 1
+        torch.cuda.synchronize()
+    preroll_ms = (time.perf_counter() - t0) * 1e3
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -170,10 +180,38 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     launch_ms = ev0.elapsed_time(ev1) / args.steps     # same stream as the kernels (torch's current stream)
+
+    # ---- same process, same buffers, same launch size: what a pure streaming kernel reaches on THIS device now ----
+    ceilings = {}
+    if not args.no_ceiling:
+        def timed(fn, reps=24):
+            for k in range(6):
+                fn(k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(reps):
+                fn(k)
+            e1.record()
+            torch.cuda.synchronize()
+            return 2.0 * set_bytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9     # every byte read once + written once
+        base = [b.data_ptr() for b in sets]
+        cus = h.device_info()["cu_count"]
+        ceilings["inplace_rmw_4KiB_per_wave_8wg_per_cu"] = timed(lambda k: h.diag_stream(0, base[k % pool], set_bytes, 1, 8 * cus, stream))
+        ceilings["inplace_rmw_4KiB_per_wave_12wg_per_cu"] = timed(lambda k: h.diag_stream(0, base[k % pool], set_bytes, 1, 12 * cus, stream))
+        ceilings["inplace_rmw_4KiB_per_wave_one_wg_per_16KiB"] = timed(lambda k: h.diag_stream(0, base[k % pool], set_bytes, 2, 0, stream))
+        ceilings["out_of_place_uint4_copy"] = timed(lambda k: h.diag_stream(base[k % pool], base[(k + 1) % pool], set_bytes, 0, 8 * cus, stream))
+
+    n_seen, per_rank_us = 1, [round(launch_ms * 1e3, 2)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        n_seen = int(one.item())
+        lus = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(lus, torch.tensor([launch_ms * 1e3], dtype=torch.float64))
+        per_rank_us = [round(float(x.item()), 2) for x in lus]
 
     if rank == 0:
         frames_total = args.steps * frames_per_launch          # whole frames finished by all ranks together
@@ -181,12 +219,28 @@ def main():
         samples_per_launch = frames_per_launch * (part_h * W + 2 * (part_h // SUBY) * (W // SUBX))
         bytes_per_launch = 4 * samples_per_launch              # 2 B read + 2 B written per sample
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "hbm_traffic.json"            # PMC-derived bytes per launch, if collected
+        # PMC-derived HBM bytes per launch: only valid for the kernel source they were collected with
+        traffic, traffic_source = None, None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists() and world == 1:
-            rec = json.loads(tf.read_text())                     # measured with rocprofv3 --pmc on this command
-            if rec.get("batch") == args.batch:
+            rec = json.loads(tf.read_text())
+            if rec.get("batch") == args.batch and rec.get("kernel_sha16") == kernel_sha():
                 traffic = rec.get("bytes_per_launch")
+                traffic_source = {"file": "profiles/hbm_traffic.json", "date": rec.get("date"), "kernel_sha16": rec.get("kernel_sha16"),
+                                  "how": rec.get("correction")}
+            else:
+                traffic_source = {"file": "profiles/hbm_traffic.json", "stale": True, "kernel_sha16_now": kernel_sha(),
+                                  "kernel_sha16_profiled": rec.get("kernel_sha16")}
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "grain_kernel<10,2,2,false>", "launch_us": round(launch_ms * 1e3, 2),
+                "algorithmic_bytes_per_launch": bytes_per_launch}
+        if ceilings:
+            best = max(ceilings.values())
+            roof["copy_ceiling_gbs"] = round(best, 1)
+            roof["frac_of_ceiling"] = round(achieved / best, 4)
+            roof["copy_ceilings_gbs"] = {k: round(v, 1) for k, v in ceilings.items()}
+            roof["copy_ceiling_note"] = "pure streaming kernels (vfgs_hip_diag_stream), same process, same buffers, same bytes per launch, measured right after the timed region"
         out = {
             "metric": "Mpixels/s (Y+UV) + achieved HBM GB/s vs roofline, 4320p 10-bit 4:2:0",
             "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,11 +248,11 @@ def main():
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": "7680x4320 10-bit 4:2:0, cfg fgs_sei (8 luma patterns), seed 12345, uniform random samples",
                        "frames_per_step": frames_per_launch, "stripe_split": f"{world} x block-row stripes",
-                       "pool_frames": pool * frames_per_launch, "msamples_per_s": round(mpix * 1.5, 1)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "grain_kernel<10,2,2,false>", "launch_us": round(launch_ms * 1e3, 2),
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                       "pool_frames": pool * frames_per_launch, "msamples_per_s": round(mpix * 1.5, 1),
+                       "preroll_ms": round(preroll_ms, 1), "preroll_launches": n_pre,
+                       "sync_backend": "gloo (barrier + max only; no collective on the data path)" if world > 1 else "none",
+                       "n_ranks_seen": n_seen, "launch_us_per_rank": per_rank_us},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()

@@ -149,6 +149,13 @@ const char* vfgs_hip_last_error_string(void);
 int vfgs_hip_timer_begin(void* stream);
 int vfgs_hip_timer_end(void* stream, float* elapsed_ms);
 
+/* Diagnostics for benchmarks (no grain arithmetic, never called by the library itself): stream `bytes` bytes
+ * once through the chip -- mode 0: out-of-place copy src -> dst (16 bytes per lane); mode 1: in-place
+ * read-modify-write of dst, persistent waves that move 4 KiB per step (`grid` workgroups of 4 waves, 0 = 8 per CU);
+ * mode 2: the same with one workgroup per 16 KiB.  Pointers and size: multiples of 16.  bench.py times these in
+ * its own process, on its own buffers, at the grain launch's size, as the copy ceiling of the chip. */
+int vfgs_hip_diag_stream(const void* src, void* dst, uint64_t bytes, int mode, int grid, void* stream);
+
 /* Introspection for benchmarks/tests. */
 int vfgs_hip_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* name, int name_len);
 

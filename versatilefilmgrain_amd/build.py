@@ -14,7 +14,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libvfgs_hip.so"
-SOURCES = [CSRC / "vfgs_kernel.hip", CSRC / "vfgs_fw_kernel.hip", CSRC / "vfgs_host.cpp", CSRC / "vfgs_fw_host.cpp", CSRC / "vfgs_cfg_host.cpp"]
+SOURCES = [CSRC / "vfgs_kernel.hip", CSRC / "vfgs_fw_kernel.hip", CSRC / "vfgs_diag.hip", CSRC / "vfgs_host.cpp", CSRC / "vfgs_fw_host.cpp", CSRC / "vfgs_cfg_host.cpp"]
 FW_TABLES = CSRC / "fw_tables.bin"   # model constants, linked into the library as data (oracle/dump_fw_tables.c)
 HEADERS = [CSRC / "vfgs_layout.h", CSRC / "vfgs_fw_layout.h", FW_TABLES,
            PKG.parent / "include" / "vfgs_hip.h", PKG.parent / "include" / "vfgs_hip_fw.h"]

@@ -26,6 +26,7 @@ namespace vfgs {
 hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, int grid, hipStream_t stream);
 int table_bytes(int csubx, int csuby);
 void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes);
+hipError_t launch_diag_stream(const void* src, void* dst, size_t bytes, int mode, int grid, int cu_count, hipStream_t stream);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
 hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby, hipStream_t stream);
 }
@@ -1309,6 +1310,16 @@ int vfgs_hip_timer_end(void* stream, float* elapsed_ms)
 	HIP_TRY(hipEventRecord(S().ev1, (hipStream_t)stream));
 	HIP_TRY(hipEventSynchronize(S().ev1));
 	HIP_TRY(hipEventElapsedTime(elapsed_ms, S().ev0, S().ev1));
+	return 0;
+}
+
+int vfgs_hip_diag_stream(const void* src, void* dst, uint64_t bytes, int mode, int grid, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (int e = ensure_init(-1)) return e;
+	if (((uintptr_t)src | (uintptr_t)dst | bytes) & 15) return fail(7, "vfgs_hip_diag_stream: pointers and size must be multiples of 16 bytes");
+	if (mode < 0 || mode > 2 || !dst || (mode == 0 && !src)) return fail(25, "vfgs_hip_diag_stream: mode %d", mode);
+	HIP_TRY(vfgs::launch_diag_stream(src, dst, (size_t)bytes, mode, grid, S().cu_count, (hipStream_t)stream));
 	return 0;
 }
 

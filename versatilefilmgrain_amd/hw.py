@@ -58,6 +58,7 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_timer_begin.argtypes = [vp]
     lib.vfgs_hip_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
     lib.vfgs_hip_device_info.argtypes = [C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
+    lib.vfgs_hip_diag_stream.argtypes = [vp, vp, C.c_uint64, i, i, vp]
     _lib = lib
     return lib
 
@@ -73,6 +74,7 @@ EXPORTS = [
     "vfgs_hip_add_grain_frames_dev", "vfgs_hip_add_grain_frames_part_dev", "vfgs_hip_add_grain_copy_dev",
     "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
+    "vfgs_hip_diag_stream",
 ]
 
 
@@ -158,6 +160,10 @@ class VfgsHip:
         out = (C.c_int * 8)()
         self.lib.vfgs_hip_get_params(out)
         return dict(zip(("scale_shift", "bs", "ymin", "ymax", "cmin", "cmax", "csubx", "csuby"), out))
+
+    def diag_stream(self, src, dst, nbytes, mode, grid=0, stream=0):
+        """Pure streaming kernels (no grain arithmetic): the copy ceiling of the chip, for bench.py."""
+        self._ck(self.lib.vfgs_hip_diag_stream(src, dst, nbytes, mode, grid, stream))
 
     def device_info(self):
         cu, lds, clk = C.c_int(), C.c_int(), C.c_int()
