@@ -37,7 +37,7 @@ def build(variant, tmp):
     cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-w", f"-DVFGS_ABLATE={parts[0]}",
            *flags, f"-I{ROOT / 'versatilefilmgrain_amd/csrc'}", f'-DVFGS_FW_TABLES_PATH="{ROOT / "versatilefilmgrain_amd/csrc/fw_tables.bin"}"',
            "-o", str(out), str(src / "vfgs_kernel.hip"), str(src / "vfgs_host.cpp")]
-    cmd += [str(src / f) for f in ("vfgs_fw_kernel.hip", "vfgs_fw_host.cpp", "vfgs_cfg_host.cpp") if (src / f).exists()]
+    cmd += [str(src / f) for f in ("vfgs_fw_kernel.hip", "vfgs_diag.hip", "vfgs_fw_host.cpp", "vfgs_cfg_host.cpp") if (src / f).exists()]
     subprocess.run(cmd, check=True, cwd=tmp)
     return out
 

@@ -704,6 +704,8 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		d.ppb = std::min<int>(phases, std::max<int>(1, (int)rpb / vfgs::kRowsPerWave));
 		d.bpw = phases / d.ppb;
 		d.splits = std::max<int>(1, (int)rpb / (d.ppb * vfgs::kRowsPerWave));
+		auto lg = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
+		d.ltiles_w = lg(d.tiles_w); d.lppb = lg(d.ppb); d.lsplits = lg(d.splits);
 		const int nbgroups = (nbr_stripe + d.bpw - 1) / d.bpw;
 		d.wgs = d.nrows > 0 ? nbgroups * d.splits * d.colgroups : 0;
 	}
@@ -747,10 +749,10 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.frame_bit_step = nframes > 1 ? (uint32_t)(second_cur - first_cur) : 0;
 
 	// one workgroup per (plane, group of rows, group of tiles), numbered in memory order; not persistent
-	const long total = ((long)a.pd[0].wgs + 2L * a.pd[1].wgs) * a.nframes;
-	if (total > 0x7fffffffL) return fail(14, "launch too large");
-	if (total == 0) return 0;
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, (int)total, stream));
+	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
+	if (per_frame > 0x7fffffffL || nframes > 65535) return fail(14, "launch too large");
+	if (per_frame == 0) return 0;
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, (int)per_frame, stream));
 	return 0;
 }
 

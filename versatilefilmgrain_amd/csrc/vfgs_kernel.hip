@@ -395,22 +395,24 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	// All wave-uniform; readfirstlane tells the compiler (runtime divisions run on the vector ALU), so that row offsets
 	// and descriptors stay in SGPRs instead of waterfall loops around every buffer instruction.
 	auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-	const int colgroup = r % pd.colgroups; r /= pd.colgroups;
-	const int split = r % pd.splits;
-	const int bgroup = r / pd.splits;
-	const int tile = uni(colgroup * pd.tiles_w + wave % pd.tiles_w);
-	const int q = wave / pd.tiles_w;
-	const int ph = q % pd.ppb;
-	const int kbr = uni(bgroup * pd.bpw + q / pd.ppb);   // block row inside the stripe
+	// (tiles_w, ppb, splits are powers of two -- shifts; only a picture wider than kWavesPerWG tiles has column groups)
+	int colgroup = 0;
+	if (pd.colgroups > 1) { colgroup = r % pd.colgroups; r /= pd.colgroups; }
+	const int split = r & (pd.splits - 1);
+	const int bgroup = r >> pd.lsplits;
+	const int tile = uni(colgroup * pd.tiles_w + (wave & (pd.tiles_w - 1)));
+	const int q = wave >> pd.ltiles_w;
+	const int ph = q & (pd.ppb - 1);
+	const int kbr = uni(bgroup * pd.bpw + (q >> pd.lppb));   // block row inside the stripe
 	const int Rabs = (a.y0 >> 4) + kbr;                  // absolute block row
 	const int row_first = (a.y0 + SUBY - 1) / SUBY;      // first row of the stripe in this plane; the plane pointers address row y0 / SUBY
 	const int prow0 = a.y0 / SUBY;
 	const bool active = (tile < pd.tiles) && (kbr < a.nbrows);
 	// rows of this block row that belong to the stripe: [alo, ahi); mine: base + ppb * k, k in [k0, k1)
 	const int alo = max(row_first, Rabs * RPB), ahi = min(row_first + pd.nrows, (Rabs + 1) * RPB);
-	const int base = uni(Rabs * RPB + split * (RPB / pd.splits) + ph);
-	const int nk = RPB / pd.splits / pd.ppb;
-	int k0 = max(0, (alo - base + pd.ppb - 1) / pd.ppb), k1 = min(nk, (max(0, ahi - base) + pd.ppb - 1) / pd.ppb);
+	const int base = uni(Rabs * RPB + split * (RPB >> pd.lsplits) + ph);
+	const int nk = (RPB >> pd.lsplits) >> pd.lppb;
+	int k0 = max(0, alo - base + pd.ppb - 1) >> pd.lppb, k1 = min(nk, (max(0, ahi - base) + pd.ppb - 1) >> pd.lppb);
 	if (!active) k1 = k0 = 0;
 	k0 = uni(k0); k1 = uni(k1);
 
@@ -600,6 +602,12 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 #if VFGS_PREFETCH
 			load_seg(nrs, vo[g], rowb + rstep, w[g]);
 #endif
+#if VFGS_SCHED_FENCE
+			// keep the refill where it is: with registers to spare hipcc's scheduler otherwise computes all four segments
+			// first and issues the four stores and the four refills together at the end of the row -- every row would then
+			// start with a full memory latency
+			__builtin_amdgcn_sched_barrier(0);
+#endif
 		}
 		rowb += rstep;
 		drowb += drstep;
@@ -647,9 +655,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3
 	// descriptors in SGPRs (otherwise every buffer instruction gets a waterfall loop)
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-	const int per_frame = a.pd[0].wgs + 2 * a.pd[1].wgs;
-	const int f = blockIdx.x / per_frame;
-	int r = blockIdx.x - f * per_frame;
+	const int f = blockIdx.y;            // grid: x = workgroup inside the frame, y = frame of the batch
+	int r = blockIdx.x;
 	if (r < a.pd[0].wgs)
 		run_plane<DEPTH, 16, 1, 1, L::LRS, OUT8>(a, a.pd[0], lds, 0, f, r, L::Y_OFF, L::Y_BYTES, L::Y_BANK, lane, wave);
 	else
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
 static hipError_t launch_t(const KernelArgs& a, int grid, hipStream_t stream)
 {
-	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY, OUT8>), dim3(grid), dim3(kWavesPerWG * 64), 0, stream, a);
+	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY, OUT8>), dim3(grid, a.nframes), dim3(kWavesPerWG * 64), 0, stream, a);
 	return hipGetLastError();
 }
 

@@ -29,6 +29,9 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_PREFETCH
 #define VFGS_PREFETCH 1   // 1: a segment's registers are refilled with the next row right after its store
 #endif
+#ifndef VFGS_SCHED_FENCE
+#define VFGS_SCHED_FENCE 1 // 1: a scheduling fence after every segment keeps its store and refill in program order
+#endif
 #ifndef VFGS_ABLATE
 #define VFGS_ABLATE 0     // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py):
                           //   1 copy only (tables still staged, block parameters still computed), 2 copy only + no staging,
@@ -95,7 +98,8 @@ struct PlaneDesc {
 	uint32_t rowbytes, drowbytes; // bytes of a row the reference touches (whole blocks)
 	int nrows;                    // rows of the stripe
 	int upt, segs, tiles;         // units per segment (<= 64), segments and tiles per row
-	int tiles_w, ppb, bpw, splits;
+	int tiles_w, ppb, bpw, splits;   // powers of two
+	int ltiles_w, lppb, lsplits;     // their logarithms
 	int colgroups;                // workgroups along a row = ceil(tiles / tiles_w)
 	int wgs;                      // workgroups per frame for ONE plane of this type
 };
