@@ -61,6 +61,21 @@ void vfgs_add_grain_line(void* Y, void* U, void* V, int y, int width);
 
 /* ---- (2) extensions ------------------------------------------------------- */
 
+/* vfgs_add_grain_line and lines the caller has not handed over yet.  One drop-in call is one line in host memory and
+ * must be complete on return (~90 us: copy in, launch, copy out).  The library therefore works ahead: on a miss it
+ * computes the lines FOLLOWING the requested one as well (up to 256), keeps those results, and serves the next calls
+ * from them when they are exactly the predicted lines with unchanged input bytes.  Lines not yet handed over are only
+ * ever READ, and only inside rows the caller has proven to own: either this same buffer (same line-0 pointers and
+ * width) has been walked top to bottom once before, or the caller has said so with vfgs_hip_declare_frame().  A first
+ * frame, or a frame in a buffer the previous walk did not go through, is computed line by line.
+ * vfgs_hip_line_lookahead(0) switches the behaviour off (so does the environment variable VFGS_HIP_LINE_LOOKAHEAD=0);
+ * vfgs_hip_declare_frame(Y, U, V, width, height, stride, cstride) (host pointers to line 0, strides in samples)
+ * promises that the three planes hold `height` lines at those pitches, which enables working ahead from the first
+ * line of the first frame on; it stays valid for walks that start at these pointers; all-NULL revokes it. */
+void vfgs_hip_line_lookahead(int enable);
+int vfgs_hip_declare_frame(const void* Y, const void* U, const void* V, unsigned width, unsigned height,
+                           unsigned stride, unsigned cstride);
+
 /* Host-memory stripe: lines y .. y+height-1, strides in samples.  Equivalent to `height`
  * consecutive vfgs_add_grain_line calls (one H2D + kernel + D2H instead of `height`). */
 void vfgs_add_grain_stripe(void* Y, void* U, void* V, unsigned y, unsigned width,

@@ -473,3 +473,80 @@ def test_long_stream_across_lfsr_window_refills(hip, name, seed):
         assert np.array_equal(dU[i].cpu().numpy().view(f.dtype).reshape(f.U.shape), f.U), i
         assert np.array_equal(dV[i].cpu().numpy().view(f.dtype).reshape(f.V.shape), f.V), i
     assert hip.seed_state() == ora.seed_state()
+
+
+def test_line_api_lookahead_only_in_proven_rows(hip):
+    """Working ahead reads lines the caller has not handed over yet, so it is confined to rows the caller has proven to
+    own (vfgs_hip.h): the SAME buffer walked once before, or a declared frame.  Pictures of different heights follow
+    each other in one buffer and in fresh buffers; a declared frame works ahead from its first line; results and seed
+    registers are the oracle's in every case."""
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    big, _ = T.lcg_frames(320, 176, depth, sx, sy, 6)
+    small, _ = T.lcg_frames(320, 112, depth, sx, sy, 3)
+    buf = big[0].copy()                                     # ONE buffer for the whole sequence
+
+    def run(src, hgt):
+        want = src.copy()
+        buf.Y[:hgt] = src.Y[:hgt]; buf.U[:hgt // 2] = src.U[:hgt // 2]; buf.V[:hgt // 2] = src.V[:hgt // 2]
+        for y in range(hgt):
+            hip.add_grain_line(buf.Y[y].ctypes.data, buf.U[y // 2].ctypes.data, buf.V[y // 2].ctypes.data, y, buf.width)
+            ora.add_grain_line(want.Y[y].ctypes.data, want.U[y // 2].ctypes.data, want.V[y // 2].ctypes.data, y, want.width)
+        assert np.array_equal(buf.Y[:hgt], want.Y[:hgt]) and np.array_equal(buf.U[:hgt // 2], want.U[:hgt // 2]) \
+            and np.array_equal(buf.V[:hgt // 2], want.V[:hgt // 2])
+        assert hip.seed_state() == ora.seed_state()
+
+    run(big[0], 176)        # first walk: line by line
+    run(big[1], 176)        # same buffer: works ahead up to line 175
+    run(small[0], 112)      # a smaller picture in the same buffer (the rows read ahead beyond 111 belong to the buffer)
+    run(small[1], 112)
+    run(big[2], 176)        # larger again: only 112 rows are proven now
+    run(big[3], 176)
+    for f in (big[4], small[2]):                            # fresh buffers: nothing is proven
+        a, b = f.copy(), f.copy()
+        _line_loop(hip, a, sy)
+        _line_loop(ora, b, sy)
+        assert a.equal_all(b)
+    # a declared frame works ahead from the first line of the first walk
+    d, want = big[5].copy(), big[5].copy()
+    hip.declare_frame(d.Y.ctypes.data, d.U.ctypes.data, d.V.ctypes.data, d.width, d.height, d.stride, d.cstride)
+    _line_loop(hip, d, sy)
+    _line_loop(ora, want, sy)
+    assert d.equal_all(want)
+    hip.declare_frame(None, None, None, 0, 0, 0, 0)
+    hip.line_lookahead(False)
+    d, want = big[0].copy(), big[0].copy()
+    _line_loop(hip, d, sy)
+    _line_loop(ora, want, sy)
+    assert d.equal_all(want) and hip.seed_state() == ora.seed_state()
+    hip.line_lookahead(True)
+
+
+def test_new_seed_per_frame_queued_behind_a_long_launch(hip):
+    """A new seed before every frame (the AFGS1 case, vfgs_fw.c:672) switches the LFSR stream image every call.  The
+    calls are asynchronous: many of them queue up behind a long launch, and every one must still read ITS image when it
+    finally runs (the images live in a small ring whose slots are only reused after their readers)."""
+    import torch
+    from gpu_util import DevFrame, stream_ptr
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    # something long in front: 6 x 4320p frames in one launch, twice
+    Wb, Hb = 7680, 4320
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bY = torch.randint(0, 1024, (6, Hb, Wb), dtype=torch.int16, device="cuda", generator=g)
+    bU = torch.randint(0, 1024, (6, Hb // 2, Wb // 2), dtype=torch.int16, device="cuda", generator=g)
+    bV = torch.randint(0, 1024, (6, Hb // 2, Wb // 2), dtype=torch.int16, device="cuda", generator=g)
+    frames, _ = T.lcg_frames(W, H, depth, sx, sy, 12)
+    devs = [DevFrame(f) for f in frames]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        hip.add_grain_frames_dev(bY.data_ptr(), bU.data_ptr(), bV.data_ptr(), Wb, Hb, Wb, Wb // 2, 6, Hb * Wb * 2, Hb * Wb // 2, stream_ptr())
+    for i, d in enumerate(devs):                            # all queued while the long launches still run
+        hip.set_seed(1000 + 17 * i)
+        hip.add_grain_frame_dev(*d.ptrs(), W, H, frames[i].stride, frames[i].cstride, stream_ptr())
+    torch.cuda.synchronize()
+    # the oracle: the two long launches advance the registers like 12 whole frames, but every small frame starts from its own seed
+    for i, f in enumerate(frames):
+        want = f.copy()
+        ora.set_seed(1000 + 17 * i)
+        ora.add_grain_frame(want)
+        assert devs[i].download().equal_all(want), i
+    assert hip.seed_state() == ora.seed_state()

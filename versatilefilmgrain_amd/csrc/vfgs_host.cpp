@@ -46,8 +46,9 @@ using vfgs::KernelArgs;
 // ------------------------------------------------------------------------------------
 // errors
 
-int g_err = 0;
-std::string g_errstr;
+// per thread: vfgs_hip_last_error_string() hands out a pointer into the string, which only this thread's next failing call changes
+thread_local int g_err = 0;
+thread_local std::string g_errstr;
 
 int fail(int code, const char* fmt, ...)
 {
@@ -150,10 +151,12 @@ public:
 		const uint32_t reg0 = window(wlo << 5);
 		const uint64_t n = std::max<uint64_t>(refill_, 2 * (whi - wlo));
 		refill_ = std::min<uint64_t>(refill_ * 4, kMaxRefill);
-		const int nxt = (cur_ < 0 ? last_ + 1 : cur_ + 1) % kSlots;
+		const int nxt = (last_ + 1) % kSlots;
 		Slot& s = slot_[nxt];
 		hipError_t e;
-		if (s.ev && (e = hipEventSynchronize(s.ev)) != hipSuccess) return e;   // normally long complete
+		// everything that ever used this slot (its upload, the kernels that read it -- on any stream, see use_begin /
+		// use_end) must be done before its pinned source and its device words are overwritten; normally long complete
+		if (s.used && (e = hipEventSynchronize(s.ev)) != hipSuccess) return e;
 		if (s.cap < n)
 		{
 			if (s.host) (void)hipHostFree(s.host);
@@ -189,12 +192,31 @@ public:
 		s.wbase = wlo;
 		s.nwords = n;
 		if ((e = hipMemcpyAsync(s.dev, s.host, n * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-		// the slot we are leaving: remember when its last reader (queued before now) is done
-		if (cur_ >= 0 && slot_[cur_].ev) (void)hipEventRecord(slot_[cur_].ev, stream);
 		cur_ = last_ = nxt;
+		if ((e = use_end(stream)) != hipSuccess) return e;        // the upload itself is the slot's first use
 		ck_word_ = wlo;
 		ck_reg_ = reg0;
 		return hipSuccess;
+	}
+
+	// Around every kernel launch that reads the current slot.  The slot's event is re-recorded behind each use; a use on
+	// another stream than the previous one first makes its stream wait for that event, so the uses form a chain and the
+	// event, once complete, vouches for ALL of them (also after a reseed abandoned the slot).
+	hipError_t use_begin(hipStream_t stream)
+	{
+		if (cur_ < 0) return hipSuccess;
+		Slot& s = slot_[cur_];
+		if (s.used && s.last_stream != stream) return hipStreamWaitEvent(stream, s.ev, 0);
+		return hipSuccess;
+	}
+	hipError_t use_end(hipStream_t stream)
+	{
+		if (cur_ < 0) return hipSuccess;
+		Slot& s = slot_[cur_];
+		const hipError_t e = hipEventRecord(s.ev, stream);
+		s.last_stream = stream;
+		s.used = true;
+		return e;
 	}
 
 	const uint32_t* dev() const { return cur_ < 0 ? nullptr : slot_[cur_].dev; }
@@ -218,7 +240,9 @@ private:
 		uint32_t* host = nullptr;
 		uint32_t* dev = nullptr;
 		uint64_t cap = 0, wbase = 0, nwords = 0;
-		hipEvent_t ev = nullptr;
+		hipEvent_t ev = nullptr;            // completes when every use of the slot so far has
+		hipStream_t last_stream = nullptr;  // stream of the most recent use
+		bool used = false;
 	};
 	Slot slot_[kSlots];
 	int cur_ = -1, last_ = -1;
@@ -236,21 +260,19 @@ struct DevRing {
 	static constexpr int N = 4;
 	void* buf[N] = {nullptr, nullptr, nullptr, nullptr};      // device images
 	uint8_t* host[N] = {nullptr, nullptr, nullptr, nullptr};  // their pinned host sources (async H2D reads them later)
-	hipEvent_t left[N] = {nullptr, nullptr, nullptr, nullptr}; // recorded when an image is replaced: its readers are done
+	hipEvent_t ev[N] = {nullptr, nullptr, nullptr, nullptr};  // completes when every use of the slot so far has (chain, as StreamCache)
+	hipStream_t last_stream[N] = {nullptr, nullptr, nullptr, nullptr};
+	bool used[N] = {false, false, false, false};
 	size_t cap[N] = {0, 0, 0, 0};
 	int cur = -1;
 
-	// the next slot, safe to overwrite (host and device side); `stream` is where the replacement is uploaded
-	hipError_t next(size_t bytes, void** dev, uint8_t** src, hipStream_t stream)
+	// the next slot, safe to overwrite (host and device side)
+	hipError_t next(size_t bytes, void** dev, uint8_t** src)
 	{
 		hipError_t e;
-		if (cur >= 0)
-		{   // everything queued so far may still read the image we are leaving
-			if (!left[cur] && (e = hipEventCreateWithFlags(&left[cur], hipEventDisableTiming)) != hipSuccess) return e;
-			if ((e = hipEventRecord(left[cur], stream)) != hipSuccess) return e;
-		}
 		const int nxt = (cur + 1) % N;
-		if (left[nxt] && (e = hipEventSynchronize(left[nxt])) != hipSuccess) return e;   // normally long complete
+		if (used[nxt] && (e = hipEventSynchronize(ev[nxt])) != hipSuccess) return e;   // normally long complete
+		if (!ev[nxt] && (e = hipEventCreateWithFlags(&ev[nxt], hipEventDisableTiming)) != hipSuccess) return e;
 		if (cap[nxt] < bytes)
 		{
 			if (buf[nxt]) (void)hipFree(buf[nxt]);
@@ -261,9 +283,23 @@ struct DevRing {
 			cap[nxt] = bytes;
 		}
 		cur = nxt;
+		used[cur] = false;
 		*dev = buf[cur];
 		*src = host[cur];
 		return hipSuccess;
+	}
+	hipError_t use_begin(hipStream_t stream)
+	{
+		if (cur >= 0 && used[cur] && last_stream[cur] != stream) return hipStreamWaitEvent(stream, ev[cur], 0);
+		return hipSuccess;
+	}
+	hipError_t use_end(hipStream_t stream)
+	{
+		if (cur < 0) return hipSuccess;
+		const hipError_t e = hipEventRecord(ev[cur], stream);
+		last_stream[cur] = stream;
+		used[cur] = true;
+		return e;
 	}
 	void* current() const { return cur < 0 ? nullptr : buf[cur]; }
 	void release()
@@ -272,8 +308,8 @@ struct DevRing {
 		{
 			if (buf[i]) (void)hipFree(buf[i]);
 			if (host[i]) (void)hipHostFree(host[i]);
-			if (left[i]) (void)hipEventDestroy(left[i]);
-			buf[i] = nullptr; host[i] = nullptr; left[i] = nullptr; cap[i] = 0;
+			if (ev[i]) (void)hipEventDestroy(ev[i]);
+			buf[i] = nullptr; host[i] = nullptr; ev[i] = nullptr; cap[i] = 0; used[i] = false; last_stream[i] = nullptr;
 		}
 		cur = -1;
 	}
@@ -314,9 +350,6 @@ struct State {
 	int8_t* dev_bank = nullptr;               // [2][kSlots][64][64]
 	int8_t* dev_raw = nullptr;                // [kSlots][32*32]
 	vfgs::FwConstants* fw_const = nullptr;    // device copy of the model constants + noise streams
-	hipStream_t image_stream = nullptr;       // stream of the most recent table / LFSR image upload
-	hipEvent_t image_ev = nullptr;            // ... recorded behind it, for calls on other streams
-	bool image_uploaded = false;
 	std::vector<vfgs::FwLaunch> fw_pending;   // generation requests not yet launched (they run on the next grain call's stream)
 	vfgs::FwLaunch fw_last{};                 // the most recent request: re-sending it unchanged (a new seed per frame with the
 	bool fw_last_valid = false;               // same model, the usual AFGS1 stream) generates nothing
@@ -333,7 +366,9 @@ struct State {
 		const uint8_t *pY = nullptr, *pU = nullptr, *pV = nullptr;
 		unsigned py = 0, pwidth = 0;
 		ptrdiff_t ypitch = 0, cpitch = 0;     // host row pitches in bytes, 0 = not yet known
-		unsigned frame_h = 0;                 // picture height, 0 = not yet known
+		unsigned frame_h = 0;                 // lines of the buffer the caller has proven to own (see line_call), 0 = unknown
+		const uint8_t *bY = nullptr, *bU = nullptr, *bV = nullptr;   // plane pointers of line 0 of the walk in progress
+		bool declared = false;                // frame_h and the pitches come from vfgs_hip_declare_frame
 		// one pre-computed stripe
 		bool valid = false;
 		uint64_t gen = 0;
@@ -366,7 +401,13 @@ int ensure_init(int device)
 {
 	State& s = S();
 	if (s.inited && (device < 0 || device == s.device))
+	{
+		// every allocation, event and launch below belongs to the library's device, whatever device the calling
+		// thread has made current in the meantime
+		int cur = -1;
+		if (hipGetDevice(&cur) != hipSuccess || cur != s.device) HIP_TRY(hipSetDevice(s.device));
 		return 0;
+	}
 	if (s.inited)
 		return fail(1, "vfgs_hip_init: already initialised on device %d", s.device);
 	int n = 0;
@@ -557,7 +598,7 @@ int upload_tables(State& s, hipStream_t stream)
 	void* dst = nullptr;
 	const int bytes = vfgs::table_bytes(s.csubx, s.csuby);
 	uint8_t* img = nullptr;
-	HIP_TRY(s.tables_ring.next(bytes, &dst, &img, stream));
+	HIP_TRY(s.tables_ring.next(bytes, &dst, &img));
 	if (s.csubx == 2 && s.csuby == 2) build_tables<2, 2>(s, img);
 	else if (s.csubx == 2 && s.csuby == 1) build_tables<2, 1>(s, img);
 	else if (s.csubx == 1 && s.csuby == 1) build_tables<1, 1>(s, img);
@@ -569,6 +610,7 @@ int upload_tables(State& s, hipStream_t stream)
 		if (int e = fw_bank_stream(s, stream)) return e;
 		HIP_TRY(vfgs::launch_fw_patch((uint8_t*)dst, s.dev_bank, s.dev_origin[0], s.dev_origin[1], s.csubx, s.csuby, stream));
 	}
+	HIP_TRY(s.tables_ring.use_end(stream));
 	s.tables_dirty = false;
 	return 0;
 }
@@ -723,24 +765,13 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		hi = std::max(hi, p.cur0 + (uint64_t)nbr_stripe * nblk);
 		hi = std::max(hi, p.up0 + nblk);
 	}
-	// Images are uploaded on the stream of the call that needs them first.  A later call on ANOTHER stream
-	// must not start before that upload: it waits for an event recorded behind the most recent upload.
-	{
-		const void* t0 = s.tables_ring.current();
-		const uint32_t* l0 = s.lfsr.dev();
-		const uint64_t b0 = s.lfsr.base_bit();
-		if (int e = upload_tables(s, stream)) return e;
-		if (int e = upload_stream(s, lo, hi, stream)) return e;
-		if (t0 != s.tables_ring.current() || l0 != s.lfsr.dev() || b0 != s.lfsr.base_bit())
-		{
-			if (!s.image_ev) HIP_TRY(hipEventCreateWithFlags(&s.image_ev, hipEventDisableTiming));
-			HIP_TRY(hipEventRecord(s.image_ev, stream));
-			s.image_stream = stream;
-			s.image_uploaded = true;
-		}
-		else if (s.image_uploaded && stream != s.image_stream)
-			HIP_TRY(hipStreamWaitEvent(stream, s.image_ev, 0));
-	}
+	// Images are uploaded on the stream of the call that needs them first; every use of an image slot (upload or kernel)
+	// is chained behind the previous one by the slot's event, so a call on ANOTHER stream starts after the upload, and a
+	// slot is only overwritten after all its readers (StreamCache::use_begin / use_end, DevRing likewise).
+	if (int e = upload_tables(s, stream)) return e;
+	if (int e = upload_stream(s, lo, hi, stream)) return e;
+	HIP_TRY(s.tables_ring.use_begin(stream));
+	HIP_TRY(s.lfsr.use_begin(stream));
 	a.tables = (const uint8_t*)s.tables_ring.current();
 	a.stream = s.lfsr.dev();
 	a.stream_bytes = (uint32_t)(s.lfsr.dev_words() * 4);
@@ -753,6 +784,8 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	if (per_frame > 0x7fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;
 	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, (int)per_frame, stream));
+	HIP_TRY(s.tables_ring.use_end(stream));
+	HIP_TRY(s.lfsr.use_end(stream));
 	return 0;
 }
 
@@ -808,19 +841,12 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 // whose input bytes still equal what was read ahead is served by a memcpy; anything else drops
 // the stripe and recomputes.  Lines the caller has not handed over are never written, the seed
 // registers advance per call exactly as before, so the observable behaviour is unchanged.
-// Until the picture height is known (first frame) the look-ahead stops at the end of the
-// 16-line block row and is guarded by mincore(); VFGS_HIP_LINE_LOOKAHEAD=0 disables it.
+// Lines are only ever read ahead inside rows the caller has PROVEN to own: either it has walked this very buffer
+// (same three line-0 pointers, same width) top to bottom once before -- then the rows up to the height of that walk
+// are known -- or it has told us with vfgs_hip_declare_frame().  A first frame, or a frame in a buffer not seen in the
+// previous walk, is computed line by line.  vfgs_hip_line_lookahead(0) or VFGS_HIP_LINE_LOOKAHEAD=0 turn it off.
 
 constexpr unsigned kMaxAhead = 256;
-
-bool mapped(const void* p, size_t len)
-{
-	const uintptr_t ps = (uintptr_t)sysconf(_SC_PAGESIZE);
-	const uintptr_t a = (uintptr_t)p & ~(ps - 1);
-	const size_t l = (((uintptr_t)p + len - a) + ps - 1) & ~(ps - 1);
-	std::vector<unsigned char> v(l / ps + 1);
-	return mincore((void*)a, l, v.data()) == 0;
-}
 
 int line_speculate(State& s, void* Y, void* U, void* V, unsigned y, unsigned width, unsigned n)
 {
@@ -937,27 +963,28 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 			else if (cU != la.pU || cV != la.pV)
 				la.cpitch = 0, la.ypitch = 0;     // not the reference's walk: no look-ahead
 		}
-		else if (la.have_prev && y == 0 && la.py > 0 && width == la.pwidth)
-			la.frame_h = la.py + 1;               // wrapped around: the previous frame had py + 1 lines
-		else if (la.have_prev)
+		else if (la.have_prev && y == 0 && la.py > 0 && width == la.pwidth && !la.declared)
+		{
+			// wrapped around.  The walk that just ended proves py + 1 rows -- of the buffer it went through: it carries
+			// over only if this walk starts in the same buffer
+			la.frame_h = (cY == la.bY && cU == la.bU && cV == la.bV) ? la.py + 1 : 0;
+		}
+		else if (la.have_prev && !la.declared)
 			la.ypitch = la.cpitch = 0, la.frame_h = 0;
+		if (y == 0)
+		{
+			if (la.declared && !(cY == la.bY && cU == la.bU && cV == la.bV && width == la.pwidth))
+				la.declared = false, la.ypitch = la.cpitch = 0, la.frame_h = 0;      // not the declared frame
+			la.bY = cY; la.bU = cU; la.bV = cV;
+		}
 
-		// 3. compute: this line alone, or this line plus the lines the caller is about to hand over
+		// 3. compute: this line alone, or this line plus the lines the caller is about to hand over (never beyond
+		// the rows it has proven to own)
 		unsigned n = 1;
 		const unsigned sz = s.bs ? 2 : 1;
 		const size_t ylen = (size_t)nblk * 16 * sz, clen = (size_t)nblk * 16 / s.csubx * sz;
-		if (la.ypitch >= (ptrdiff_t)ylen && la.cpitch >= (ptrdiff_t)clen && width > 128)
-		{
-			const unsigned limit = (la.frame_h > y) ? la.frame_h : ((y | 15) + 1);
-			n = std::min(limit - y, kMaxAhead);
-			if (n > 1 && la.frame_h <= y)     // height still unknown: never read unmapped memory
-			{
-				const size_t crows = (y + n - 1) / s.csuby - y / s.csuby + 1;
-				if (!mapped(cY, (size_t)(n - 1) * la.ypitch + ylen) || !mapped(cU, (crows - 1) * la.cpitch + clen) ||
-				    !mapped(cV, (crows - 1) * la.cpitch + clen))
-					n = 1;
-			}
-		}
+		if (la.ypitch >= (ptrdiff_t)ylen && la.cpitch >= (ptrdiff_t)clen && width > 128 && la.frame_h > y)
+			n = std::min(la.frame_h - y, kMaxAhead);
 		rc = (n > 1) ? line_speculate(s, Y, U, V, y, width, n) : run_host(Y, U, V, y, width, 1, 0, 0);
 	}
 	la.have_prev = true;
@@ -1091,6 +1118,32 @@ void vfgs_add_grain_stripe(void* Y, void* U, void* V, unsigned y, unsigned width
 		die("vfgs_add_grain_stripe");
 }
 
+void vfgs_hip_line_lookahead(int enable)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().la.enabled = enable != 0;
+	S().la.valid = false;
+}
+
+int vfgs_hip_declare_frame(const void* Y, const void* U, const void* V, unsigned width, unsigned height, unsigned stride, unsigned cstride)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	State::LineAhead& la = s.la;
+	const unsigned sz = s.bs ? 2 : 1, nblk = (width + 15) / 16;
+	if (!Y || !U || !V || height == 0) { la.declared = false; la.frame_h = 0; la.ypitch = la.cpitch = 0; la.valid = false; return 0; }
+	if (stride < nblk * 16 || cstride < nblk * 16 / s.csubx)
+		return fail(6, "vfgs_hip_declare_frame: stride %u/%u too small: whole 16-sample blocks are written (need >= %u/%u)", stride, cstride, nblk * 16, nblk * 16 / s.csubx);
+	la.declared = true;
+	la.bY = (const uint8_t*)Y; la.bU = (const uint8_t*)U; la.bV = (const uint8_t*)V;
+	la.pwidth = width;
+	la.frame_h = height;
+	la.ypitch = (ptrdiff_t)stride * sz; la.cpitch = (ptrdiff_t)cstride * sz;
+	la.have_prev = false;
+	la.valid = false;
+	return 0;
+}
+
 void vfgs_hip_reset_state(void)
 {
 	std::lock_guard<std::mutex> g(g_mu);
@@ -1144,8 +1197,6 @@ void vfgs_hip_shutdown(void)
 	if (s.dev_bank) (void)hipFree(s.dev_bank);
 	if (s.dev_raw) (void)hipFree(s.dev_raw);
 	if (s.bank_ev) (void)hipEventDestroy(s.bank_ev);
-	if (s.image_ev) (void)hipEventDestroy(s.image_ev);
-	s.image_ev = nullptr; s.image_uploaded = false; s.image_stream = nullptr;
 	s.fw_const = nullptr; s.dev_bank = nullptr; s.dev_raw = nullptr; s.bank_ev = nullptr;
 	s.bank_used = false; s.bank_stream = nullptr;
 	s.dev_origin[0] = s.dev_origin[1] = 0;

@@ -59,6 +59,9 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
     lib.vfgs_hip_device_info.argtypes = [C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
     lib.vfgs_hip_diag_stream.argtypes = [vp, vp, C.c_uint64, i, i, vp]
+    lib.vfgs_hip_line_lookahead.argtypes = [i]
+    lib.vfgs_hip_line_lookahead.restype = None
+    lib.vfgs_hip_declare_frame.argtypes = [vp, vp, vp, u, u, u, u]
     _lib = lib
     return lib
 
@@ -74,7 +77,7 @@ EXPORTS = [
     "vfgs_hip_add_grain_frames_dev", "vfgs_hip_add_grain_frames_part_dev", "vfgs_hip_add_grain_copy_dev",
     "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
-    "vfgs_hip_diag_stream",
+    "vfgs_hip_diag_stream", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
 ]
 
 
@@ -160,6 +163,12 @@ class VfgsHip:
         out = (C.c_int * 8)()
         self.lib.vfgs_hip_get_params(out)
         return dict(zip(("scale_shift", "bs", "ymin", "ymax", "cmin", "cmax", "csubx", "csuby"), out))
+
+    def line_lookahead(self, enable):
+        self.lib.vfgs_hip_line_lookahead(1 if enable else 0)
+
+    def declare_frame(self, Y, U, V, width, height, stride, cstride):
+        self._ck(self.lib.vfgs_hip_declare_frame(Y, U, V, width, height, stride, cstride))
 
     def diag_stream(self, src, dst, nbytes, mode, grid=0, stream=0):
         """Pure streaming kernels (no grain arithmetic): the copy ceiling of the chip, for bench.py."""
