@@ -124,6 +124,23 @@ def record_fwcfg(depth, fmt, cfg, dst):
     np.savez_compressed(dst, kinds=np.array(kinds, dtype=np.int32), seed=np.array([SEED], dtype=np.uint32), **blobs)
 
 
+DERIVED_440 = ["fgs_sei_10_444", "fgs_afgs1_test1_8_444", "fgs_afgs1_test1_10_444", "fgs_sei_ff_test6_10_444"]
+
+
+def derive_440():
+    """The hardware layer accepts csubx = 1, csuby = 2 (vfgs_hw.c:382-388) but the reference CLI has no such
+    format (-f 420 | 422 | 444).  Programming sequences for it are therefore derived from the recorded 4:4:4
+    ones: identical setter calls, only vfgs_set_chroma_subsampling(1, 1) becomes (1, 2) -- which also changes
+    what the following vfgs_set_chroma_pattern calls copy (vfgs_hw.c:320-325).  Expected outputs come from the
+    real hardware layer driven directly (tests/test_oracle_vs_reference.py), not from the CLI."""
+    for name in DERIVED_440:
+        rec = T.load_trace(name)
+        out = [(op, a, 2 if op == T.OP_CHROMA_SUBSAMPLING else b, p) for op, a, b, p in rec]
+        assert any(op == T.OP_CHROMA_SUBSAMPLING and (a, b) == (1, 2) for op, a, b, _ in out), name
+        T.save_trace_npz(out, T.TRACES / f"{name[:-3]}440.npz")
+        print("derived", f"{name[:-3]}440")
+
+
 def fwcfg_only():
     (T.GOLDEN / "fwcfg").mkdir(parents=True, exist_ok=True)
     cfgs = sorted(p.stem for p in CFG.glob("*.cfg"))
@@ -155,6 +172,7 @@ def extras_only():
             md5["small"][name] = run_ref(w, h, depth, fmt, cfg, n, inp, out)
             print(name, md5["small"][name], flush=True)
     (T.GOLDEN / "md5.json").write_text(json.dumps(md5, indent=1, sort_keys=True) + "\n")
+    derive_440()
     cfg_corpus()
 
 
@@ -210,6 +228,7 @@ def main():
             os.unlink(out)
 
     (T.GOLDEN / "md5.json").write_text(json.dumps(md5, indent=1, sort_keys=True) + "\n")
+    derive_440()
     cfg_corpus()
 
 

@@ -10,7 +10,7 @@ import vfgs_testlib as T
 pytestmark = pytest.mark.gpu
 
 MD5 = json.loads((T.GOLDEN / "md5.json").read_text())
-SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1)}
+SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1), "440": (1, 2)}   # "440": csubx 1, csuby 2 (hw layer only; derived traces, make_golden.py)
 W, H, N = 192, 144, 3
 
 
@@ -53,7 +53,7 @@ def test_small_frames_host_stripe_vs_golden_md5_and_oracle(hip, name):
     assert T.md5_frames(frames) == MD5["small"][name]
 
 
-@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_ff_test6_8_422", "fgs_sei_ar_test1_8_420"])
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_ff_test6_8_422", "fgs_sei_ar_test1_8_420", "fgs_sei_ff_test6_10_440"])
 def test_line_api_matches_oracle_line_by_line(hip, name):
     """The drop-in entry point itself: one call per line, host pointers, in order."""
     ora, (depth, sx, sy) = program(hip, name)
@@ -78,7 +78,7 @@ def test_line_api_arbitrary_order(hip):
     assert hip.seed_state() == ora.seed_state()
 
 
-@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_sei_8_422", "fgs_afgs1_test1_10_444", "fgs_sei_ff_test6_10_444"])
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_sei_8_422", "fgs_afgs1_test1_10_444", "fgs_sei_ff_test6_10_444", "fgs_sei_10_440", "fgs_afgs1_test1_8_440"])
 @pytest.mark.parametrize("width,height", [(200, 152), (136, 130), (1000, 160)])
 def test_ragged_sizes_garbage_padding_and_out_of_range(hip, name, width, height):
     """W % 16 != 0 (whole last block is processed in the stride padding, quirk 7), stripes that
@@ -171,7 +171,7 @@ def test_frame_parts_equal_whole_frame_and_keep_seeds(hip):
 
 def test_out_of_place_equals_in_place_and_keeps_source(hip):
     from gpu_util import DevFrame, stream_ptr
-    for name in ("fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_ff_test6_8_422"):
+    for name in ("fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_ff_test6_8_422", "fgs_afgs1_test1_10_440"):
         ora, (depth, sx, sy) = program(hip, name)
         f, _ = T.lcg_frames(456, 304, depth, sx, sy, 1)
         f = f[0]
@@ -282,11 +282,13 @@ def test_fused_8bit_output_matches_reference_outdepth8(hip, name):
     assert m.hexdigest() == MD5["small_outdepth8"][name]
 
 
-def test_fused_8bit_output_batch_and_parts_444(hip):
-    """copy8 with nframes > 1, a 16-aligned part, and 4:4:4 (16-sample chroma blocks)."""
+@pytest.mark.parametrize("name", ["fgs_sei_ff_test6_10_444", "fgs_sei_ff_test6_10_440", "fgs_sei_10_422"])
+def test_fused_8bit_output_batch_and_parts_other_formats(hip, name):
+    """copy8 with nframes > 1, a 16-aligned part, and the chroma formats the CLI cannot drive (16-sample chroma blocks,
+    with and without vertical subsampling; 8-sample blocks without)."""
     import torch
     from gpu_util import stream_ptr
-    ora, (depth, sx, sy) = program(hip, "fgs_sei_ff_test6_10_444")
+    ora, (depth, sx, sy) = program(hip, name)
     n, w, h = 3, 328, 176
     frames, _ = T.lcg_frames(w, h, depth, sx, sy, n)
     want = [f.copy() for f in frames]
@@ -301,18 +303,19 @@ def test_fused_8bit_output_batch_and_parts_444(hip):
     dU = torch.zeros((n,) + f8.U.shape, dtype=torch.uint8, device="cuda")
     dV = torch.zeros((n,) + f8.V.shape, dtype=torch.uint8, device="cuda")
     py, ph = 48, 96
+    cy, ch, cw = py // sy, ph // sy, w // sx
     sz = 2
-    hip.add_grain_copy8_dev(Y.data_ptr() + py * f0.stride * sz, U.data_ptr() + py * f0.cstride * sz, V.data_ptr() + py * f0.cstride * sz,
-                            dY.data_ptr() + py * f8.stride, dU.data_ptr() + py * f8.cstride, dV.data_ptr() + py * f8.cstride,
+    hip.add_grain_copy8_dev(Y.data_ptr() + py * f0.stride * sz, U.data_ptr() + cy * f0.cstride * sz, V.data_ptr() + cy * f0.cstride * sz,
+                            dY.data_ptr() + py * f8.stride, dU.data_ptr() + cy * f8.cstride, dV.data_ptr() + cy * f8.cstride,
                             w, h, py, ph, f0.stride, f0.cstride, f8.stride, f8.cstride, n,
                             Y[0].numel(), U[0].numel(), dY[0].numel(), dU[0].numel(), stream_ptr())
     torch.cuda.synchronize()
     for i, wf in enumerate(want):
-        for got, w16 in ((dY[i], wf.Y), (dU[i], wf.U), (dV[i], wf.V)):
+        for got, w16, r0, nr, nc in ((dY[i], wf.Y, py, ph, w), (dU[i], wf.U, cy, ch, cw), (dV[i], wf.V, cy, ch, cw)):
             g = got.cpu().numpy()
-            exp = ((w16[py:py + ph, :w].astype(np.int32) + 2) >> 2).astype(np.uint8)
-            assert np.array_equal(g[py:py + ph, :w], exp)
-            assert (g[:py] == 0).all() and (g[py + ph:] == 0).all()
+            exp = ((w16[r0:r0 + nr, :nc].astype(np.int32) + 2) >> 2).astype(np.uint8)
+            assert np.array_equal(g[r0:r0 + nr, :nc], exp)
+            assert (g[:r0] == 0).all() and (g[r0 + nr:] == 0).all()
     assert hip.seed_state() == ora.seed_state()
 
 
@@ -407,7 +410,8 @@ def test_fuzz_sizes_formats_and_stripes(hip):
     from gpu_util import DevFrame, stream_ptr
     rng = np.random.default_rng(20260403)
     names = ["fgs_sei_10_420", "fgs_sei_8_422", "fgs_afgs1_test1_10_444", "fgs_sei_ff_test6_10_444", "fgs_afgs1_test1_8_444",
-             "fgs_sei_ff_test6_8_422", "fgs_sei_ar_test1_8_420", "fgs_sei_10_422"]
+             "fgs_sei_ff_test6_8_422", "fgs_sei_ar_test1_8_420", "fgs_sei_10_422", "fgs_sei_10_440", "fgs_afgs1_test1_8_440",
+             "fgs_sei_ff_test6_10_440"]
     for it in range(48):
         name = names[it % len(names)]
         ora, (depth, sx, sy) = program(hip, name)

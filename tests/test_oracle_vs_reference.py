@@ -13,7 +13,7 @@ import vfgs_testlib as T
 pytestmark = [pytest.mark.reference,
               pytest.mark.skipif(not T.have_reference(), reason="oracle/_ref not built (no /root/reference here)")]
 
-SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1)}
+SUB = {"420": (2, 2), "422": (2, 1), "444": (1, 1), "440": (1, 2)}
 
 
 def pair(name):
@@ -43,7 +43,7 @@ def test_every_cfg_full_buffer(name):
         assert a.equal_all(c)
 
 
-@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_8_422"])
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_444", "fgs_sei_8_422", "fgs_sei_10_440"])
 def test_out_of_range_samples(name):
     """10-bit containers holding up to 16-bit garbage: intensity wraps as a uint8 (quirk 8)."""
     ref, ora, (depth, sx, sy) = pair(name)
