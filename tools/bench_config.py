@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Developer tool: ONE BASELINE.json configuration on one MI355X, device-resident frames, in place.
+`python3 tools/bench_config.py --config 0..4 [--batch 8] [--steps 200]` prints one JSON line; run directly behind
+`rocprofv3 --kernel-trace --stats -- python3 tools/bench_config.py ...` for the per-config kernel statistics
+kept under profiles/ (tools/gpu_profiles.sh)."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import torch  # noqa: E402
+import vfgs_testlib as T  # noqa: E402
+from versatilefilmgrain_amd import hw  # noqa: E402
+
+CONFIGS = [  # BASELINE.json configs[i]: name, w, h, depth, (subx, suby), trace, kernel
+    ("1920x1080 10-bit 4:2:0 fgs_sei", 1920, 1080, 10, (2, 2), "fgs_sei_10_420", "grain_kernel<10, 2, 2, false>"),
+    ("1920x1080 10-bit 4:2:0 fgs_sei_ff_test1", 1920, 1080, 10, (2, 2), "fgs_sei_ff_test1_10_420", "grain_kernel<10, 2, 2, false>"),
+    ("3840x2160 10-bit 4:2:0 fgs_sei_ar_test1", 3840, 2160, 10, (2, 2), "fgs_sei_ar_test1_10_420", "grain_kernel<10, 2, 2, false>"),
+    ("3840x2160 8-bit 4:4:4 fgs_afgs1_test1", 3840, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", "grain_kernel<8, 1, 1, false>"),
+    ("7680x4320 10-bit 4:2:0 fgs_sei", 7680, 4320, 10, (2, 2), "fgs_sei_10_420", "grain_kernel<10, 2, 2, false>"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, required=True)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--preroll-ms", type=float, default=150.0)
+    args = ap.parse_args()
+    name, w, hh, depth, (sx, sy), trace, kernel = CONFIGS[args.config]
+    h = hw.VfgsHip(device=0)
+    T.replay(h, T.load_trace(trace))
+    dt = torch.int16 if depth > 8 else torch.uint8
+    sz = 2 if depth > 8 else 1
+    g = torch.Generator(device="cuda").manual_seed(3)
+    frame_bytes = sz * (w * hh + 2 * (w // sx) * (hh // sy))
+    pool = max(3, int(1.5e9 // (frame_bytes * args.batch)) + 1)       # cycle through > 1.5 GB: nothing is served by the Infinity Cache
+    pool = min(pool, 64)
+
+    def mk(rows, cols):
+        return torch.randint(0, 1 << depth, (args.batch, rows, cols), dtype=torch.int32, device="cuda", generator=g).to(dt)
+    sets = [(mk(hh, w), mk(hh // sy, w // sx), mk(hh // sy, w // sx)) for _ in range(pool)]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        Y, U, V = sets[i % pool]
+        h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, w, w // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, st)
+    t0, n = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < args.preroll_ms:
+        for _ in range(8):
+            step(n)
+            n += 1
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(args.steps):
+        step(i)
+    e1.record()
+    torch.cuda.synchronize()
+    launch_us = e0.elapsed_time(e1) / args.steps * 1e3
+    us = launch_us / args.batch
+    samples = w * hh * (1 + 2 / (sx * sy))
+    nbytes = 2 * sz * samples
+    print(json.dumps({"config": args.config, "workload": name, "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
+                      "launch_us": round(launch_us, 2), "us_per_frame": round(us, 3), "algorithmic_bytes_per_frame": int(nbytes),
+                      "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 4),
+                      "Mpixels_per_s": round(w * hh / us, 1), "Msamples_per_s": round(samples / us, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,10 @@ __asm__(".section .rodata\n.balign 16\n.hidden vfgs_fw_blob\n.globl vfgs_fw_blob
 #endif
 extern "C" const unsigned char vfgs_fw_blob[], vfgs_fw_blob_end[];
 
+#ifndef VFGS_MIN_ROUNDS
+#define VFGS_MIN_ROUNDS 3   // a launch should fill the chip's wave slots at least this many times (else: fewer rows per wave)
+#endif
+
 namespace {
 
 using vfgs::KernelArgs;
@@ -90,6 +94,73 @@ uint32_t lfsr_step(uint32_t r)
 	return (r >> 1) | ((((r >> 1) ^ (r >> 29)) & 1u) << 31);
 }
 
+// Lifetime of one image slot (LFSR stream window or table image) of a small ring.  The image is uploaded on the stream of
+// the call that needs it first and then read by kernels on whatever streams the caller uses; the slot may be overwritten
+// (pinned source and device copy) only after all of that has finished.  Steady-state launches must not pay for this --
+// an event record between two kernels costs microseconds -- so nothing is recorded per launch: the guard remembers the
+// (few) streams that used the slot, other streams wait once for the upload, and when the slot is LEFT (a refill, a new
+// table image, a new seed) one event is recorded behind the last use on each of those streams.
+struct SlotGuard {
+	static constexpr int kMaxUsers = 4;
+	hipEvent_t upload_ev = nullptr, leave_ev[kMaxUsers] = {nullptr, nullptr, nullptr, nullptr};
+	hipStream_t users[kMaxUsers] = {nullptr, nullptr, nullptr, nullptr};   // distinct streams that used the slot since its upload
+	int nusers = 0, nleft = 0;
+	bool live = false;              // uploaded and not yet left
+
+	hipError_t uploaded(hipStream_t stream)
+	{
+		hipError_t e;
+		if (!upload_ev && (e = hipEventCreateWithFlags(&upload_ev, hipEventDisableTiming)) != hipSuccess) return e;
+		if ((e = hipEventRecord(upload_ev, stream)) != hipSuccess) return e;
+		users[0] = stream; nusers = 1; nleft = 0; live = true;
+		return hipSuccess;
+	}
+	// before a launch on `stream` that reads the slot
+	hipError_t use(hipStream_t stream)
+	{
+		for (int i = 0; i < nusers; i++) if (users[i] == stream) return hipSuccess;
+		hipError_t e;
+		if ((e = hipStreamWaitEvent(stream, upload_ev, 0)) != hipSuccess) return e;       // (users[0] uploaded it)
+		if (nusers == kMaxUsers)
+		{   // more streams than we track: let the oldest one drain now, then forget it
+			if ((e = hipStreamSynchronize(users[1])) != hipSuccess) return e;
+			for (int i = 1; i + 1 < nusers; i++) users[i] = users[i + 1];
+			nusers--;
+		}
+		users[nusers++] = stream;
+		return hipSuccess;
+	}
+	// the slot stops being the current one: remember when its readers are done
+	hipError_t leave()
+	{
+		if (!live) return hipSuccess;
+		hipError_t e;
+		for (int i = 0; i < nusers; i++)
+		{
+			if (!leave_ev[i] && (e = hipEventCreateWithFlags(&leave_ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+			if ((e = hipEventRecord(leave_ev[i], users[i])) != hipSuccess) return e;
+		}
+		nleft = nusers; nusers = 0; live = false;
+		return hipSuccess;
+	}
+	// before the slot is overwritten
+	hipError_t wait_free()
+	{
+		hipError_t e;
+		if (live && (e = leave()) != hipSuccess) return e;
+		for (int i = 0; i < nleft; i++)
+			if ((e = hipEventSynchronize(leave_ev[i])) != hipSuccess) return e;   // normally long complete
+		nleft = 0;
+		return hipSuccess;
+	}
+	void destroy()
+	{
+		if (upload_ev) (void)hipEventDestroy(upload_ev);
+		for (hipEvent_t& ev : leave_ev) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
+		upload_ev = nullptr; nusers = nleft = 0; live = false;
+	}
+};
+
 // Host + device image of a window of the stream, in a small ring of slots (pinned host
 // words + device words) so that a refill never overwrites what queued kernels still read.
 class StreamCache {
@@ -103,6 +174,7 @@ public:
 		seed_reg_ = reg;
 		ck_word_ = 0;
 		ck_reg_ = reg;
+		if (cur_ >= 0) (void)slot_[cur_].guard.leave();    // kernels queued so far still read it
 		cur_ = -1;   // nothing valid; slots keep their allocations
 		// A new seed per frame is the normal case for AFGS1 (vfgs_fw.c:672), so the first window after a
 		// reseed is only as large as the call needs; a stream that keeps being consumed grows its refills.
@@ -154,9 +226,10 @@ public:
 		const int nxt = (last_ + 1) % kSlots;
 		Slot& s = slot_[nxt];
 		hipError_t e;
-		// everything that ever used this slot (its upload, the kernels that read it -- on any stream, see use_begin /
-		// use_end) must be done before its pinned source and its device words are overwritten; normally long complete
-		if (s.used && (e = hipEventSynchronize(s.ev)) != hipSuccess) return e;
+		// its upload and every kernel that read it, on any stream, must be done before its pinned source and its device
+		// words are overwritten (SlotGuard); normally long complete
+		if (cur_ >= 0 && (e = slot_[cur_].guard.leave()) != hipSuccess) return e;
+		if ((e = s.guard.wait_free()) != hipSuccess) return e;
 		if (s.cap < n)
 		{
 			if (s.host) (void)hipHostFree(s.host);
@@ -167,7 +240,6 @@ public:
 			if ((e = hipMalloc((void**)&s.dev, cap * 4)) != hipSuccess) return e;
 			s.cap = cap;
 		}
-		if (!s.ev && (e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming)) != hipSuccess) return e;
 		// 32 words bit by bit, then W[n] = W[n-31] ^ W[n-3] (valid from word 32 of any base)
 		uint32_t reg = reg0;
 		uint64_t i = 0;
@@ -193,31 +265,14 @@ public:
 		s.nwords = n;
 		if ((e = hipMemcpyAsync(s.dev, s.host, n * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
 		cur_ = last_ = nxt;
-		if ((e = use_end(stream)) != hipSuccess) return e;        // the upload itself is the slot's first use
+		if ((e = s.guard.uploaded(stream)) != hipSuccess) return e;
 		ck_word_ = wlo;
 		ck_reg_ = reg0;
 		return hipSuccess;
 	}
 
-	// Around every kernel launch that reads the current slot.  The slot's event is re-recorded behind each use; a use on
-	// another stream than the previous one first makes its stream wait for that event, so the uses form a chain and the
-	// event, once complete, vouches for ALL of them (also after a reseed abandoned the slot).
-	hipError_t use_begin(hipStream_t stream)
-	{
-		if (cur_ < 0) return hipSuccess;
-		Slot& s = slot_[cur_];
-		if (s.used && s.last_stream != stream) return hipStreamWaitEvent(stream, s.ev, 0);
-		return hipSuccess;
-	}
-	hipError_t use_end(hipStream_t stream)
-	{
-		if (cur_ < 0) return hipSuccess;
-		Slot& s = slot_[cur_];
-		const hipError_t e = hipEventRecord(s.ev, stream);
-		s.last_stream = stream;
-		s.used = true;
-		return e;
-	}
+	// before every kernel launch on `stream` that reads the current slot
+	hipError_t use(hipStream_t stream) { return cur_ < 0 ? hipSuccess : slot_[cur_].guard.use(stream); }
 
 	const uint32_t* dev() const { return cur_ < 0 ? nullptr : slot_[cur_].dev; }
 	uint64_t base_bit() const { return cur_ < 0 ? 0 : slot_[cur_].wbase << 5; }
@@ -229,7 +284,7 @@ public:
 		{
 			if (s.host) (void)hipHostFree(s.host);
 			if (s.dev) (void)hipFree(s.dev);
-			if (s.ev) (void)hipEventDestroy(s.ev);
+			s.guard.destroy();
 			s = Slot{};
 		}
 		cur_ = -1;
@@ -240,9 +295,7 @@ private:
 		uint32_t* host = nullptr;
 		uint32_t* dev = nullptr;
 		uint64_t cap = 0, wbase = 0, nwords = 0;
-		hipEvent_t ev = nullptr;            // completes when every use of the slot so far has
-		hipStream_t last_stream = nullptr;  // stream of the most recent use
-		bool used = false;
+		SlotGuard guard;
 	};
 	Slot slot_[kSlots];
 	int cur_ = -1, last_ = -1;
@@ -260,9 +313,7 @@ struct DevRing {
 	static constexpr int N = 4;
 	void* buf[N] = {nullptr, nullptr, nullptr, nullptr};      // device images
 	uint8_t* host[N] = {nullptr, nullptr, nullptr, nullptr};  // their pinned host sources (async H2D reads them later)
-	hipEvent_t ev[N] = {nullptr, nullptr, nullptr, nullptr};  // completes when every use of the slot so far has (chain, as StreamCache)
-	hipStream_t last_stream[N] = {nullptr, nullptr, nullptr, nullptr};
-	bool used[N] = {false, false, false, false};
+	SlotGuard guard[N];
 	size_t cap[N] = {0, 0, 0, 0};
 	int cur = -1;
 
@@ -270,9 +321,9 @@ struct DevRing {
 	hipError_t next(size_t bytes, void** dev, uint8_t** src)
 	{
 		hipError_t e;
+		if (cur >= 0 && (e = guard[cur].leave()) != hipSuccess) return e;
 		const int nxt = (cur + 1) % N;
-		if (used[nxt] && (e = hipEventSynchronize(ev[nxt])) != hipSuccess) return e;   // normally long complete
-		if (!ev[nxt] && (e = hipEventCreateWithFlags(&ev[nxt], hipEventDisableTiming)) != hipSuccess) return e;
+		if ((e = guard[nxt].wait_free()) != hipSuccess) return e;
 		if (cap[nxt] < bytes)
 		{
 			if (buf[nxt]) (void)hipFree(buf[nxt]);
@@ -283,24 +334,12 @@ struct DevRing {
 			cap[nxt] = bytes;
 		}
 		cur = nxt;
-		used[cur] = false;
 		*dev = buf[cur];
 		*src = host[cur];
 		return hipSuccess;
 	}
-	hipError_t use_begin(hipStream_t stream)
-	{
-		if (cur >= 0 && used[cur] && last_stream[cur] != stream) return hipStreamWaitEvent(stream, ev[cur], 0);
-		return hipSuccess;
-	}
-	hipError_t use_end(hipStream_t stream)
-	{
-		if (cur < 0) return hipSuccess;
-		const hipError_t e = hipEventRecord(ev[cur], stream);
-		last_stream[cur] = stream;
-		used[cur] = true;
-		return e;
-	}
+	hipError_t uploaded(hipStream_t stream) { return cur < 0 ? hipSuccess : guard[cur].uploaded(stream); }
+	hipError_t use(hipStream_t stream) { return cur < 0 ? hipSuccess : guard[cur].use(stream); }
 	void* current() const { return cur < 0 ? nullptr : buf[cur]; }
 	void release()
 	{
@@ -308,8 +347,8 @@ struct DevRing {
 		{
 			if (buf[i]) (void)hipFree(buf[i]);
 			if (host[i]) (void)hipHostFree(host[i]);
-			if (ev[i]) (void)hipEventDestroy(ev[i]);
-			buf[i] = nullptr; host[i] = nullptr; ev[i] = nullptr; cap[i] = 0; used[i] = false; last_stream[i] = nullptr;
+			guard[i].destroy();
+			buf[i] = nullptr; host[i] = nullptr; cap[i] = 0;
 		}
 		cur = -1;
 	}
@@ -610,7 +649,7 @@ int upload_tables(State& s, hipStream_t stream)
 		if (int e = fw_bank_stream(s, stream)) return e;
 		HIP_TRY(vfgs::launch_fw_patch((uint8_t*)dst, s.dev_bank, s.dev_origin[0], s.dev_origin[1], s.csubx, s.csuby, stream));
 	}
-	HIP_TRY(s.tables_ring.use_end(stream));
+	HIP_TRY(s.tables_ring.uploaded(stream));
 	s.tables_dirty = false;
 	return 0;
 }
@@ -717,39 +756,55 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.nframes = (int)nframes;
 	a.lo2[0] = (uint32_t)(s.ymin << s.bs) * 0x10001u; a.hi2[0] = (uint32_t)(s.ymax << s.bs) * 0x10001u;
 	a.lo2[1] = (uint32_t)(s.cmin << s.bs) * 0x10001u; a.hi2[1] = (uint32_t)(s.cmax << s.bs) * 0x10001u;
-	for (int pt = 0; pt < 2; pt++)
+	// Rows a wave walks (its block parameters are computed once for them): vfgs::kRowsPerWave when the launch has work for
+	// several rounds of the chip's wave slots, fewer for small launches, which need the parallelism more than the reuse.
+	int rows_per_wave = vfgs::kRowsPerWave;
+	for (int pass = 0; pass < 2; pass++)
 	{
-		// geometry of the plane type: lanes of 16 bytes, segments of <= 64 lanes, tiles of 4 segments, and the
-		// shape of a workgroup (vfgs_layout.h PlaneDesc, vfgs_kernel.hip "Lanes")
-		vfgs::PlaneDesc& d = a.pd[pt];
-		const unsigned subx = pt ? s.csubx : 1, suby = pt ? s.csuby : 1;
-		const unsigned bw = 16 / subx, rpb = 16 / suby;
-		d.pitch = (pt ? cstride : stride) * sz;
-		d.dpitch = dg.out8 ? (pt ? dg.cstride : dg.stride) : d.pitch;
-		d.extent = (uint32_t)(pt ? cext : yext);
-		d.dextent = dg.out8 ? (uint32_t)(pt ? crows * dg.cstride : (uint64_t)part_h * dg.stride) : d.extent;
-		d.fpitch = pt ? cpitch : ypitch;
-		d.dfpitch = dg.out8 ? (pt ? dg.cpitch : dg.ypitch) : d.fpitch;
-		d.rowbytes = nblk * bw * sz;
-		d.drowbytes = dg.out8 ? nblk * bw : d.rowbytes;
-		d.nrows = pt ? (int)((part_y + part_h + suby - 1) / suby) - (int)((part_y + suby - 1) / suby) : (int)part_h;
-		int shift_samples = 0, lanes = 0;
-		vfgs::lane_layout(8 + s.bs, (int)bw, (int)nblk, &shift_samples, &lanes);
-		d.segs = (lanes + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
-		d.upt = (lanes + d.segs - 1) / d.segs;
-		if (d.upt & 1) d.upt++;                     // even: the lanes of a pair (and their roles) stay together in every segment
-		d.tiles = (d.segs + vfgs::kSegsPerTile - 1) / vfgs::kSegsPerTile;
-		d.tiles_w = 1;
-		while (d.tiles_w < d.tiles && d.tiles_w < vfgs::kWavesPerWG) d.tiles_w *= 2;
-		d.colgroups = (d.tiles + d.tiles_w - 1) / d.tiles_w;
-		const int phases = vfgs::kWavesPerWG / d.tiles_w;
-		d.ppb = std::min<int>(phases, std::max<int>(1, (int)rpb / vfgs::kRowsPerWave));
-		d.bpw = phases / d.ppb;
-		d.splits = std::max<int>(1, (int)rpb / (d.ppb * vfgs::kRowsPerWave));
-		auto lg = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
-		d.ltiles_w = lg(d.tiles_w); d.lppb = lg(d.ppb); d.lsplits = lg(d.splits);
-		const int nbgroups = (nbr_stripe + d.bpw - 1) / d.bpw;
-		d.wgs = d.nrows > 0 ? nbgroups * d.splits * d.colgroups : 0;
+		long waves = 0;
+		for (int pt = 0; pt < 2; pt++)
+		{
+			// geometry of the plane type: lanes of 16 bytes, segments of <= 64 lanes, tiles of 4 segments, and the
+			// shape of a workgroup (vfgs_layout.h PlaneDesc, vfgs_kernel.hip "Lanes")
+			vfgs::PlaneDesc& d = a.pd[pt];
+			const unsigned subx = pt ? s.csubx : 1, suby = pt ? s.csuby : 1;
+			const unsigned bw = 16 / subx, rpb = 16 / suby;
+			d.pitch = (pt ? cstride : stride) * sz;
+			d.dpitch = dg.out8 ? (pt ? dg.cstride : dg.stride) : d.pitch;
+			d.extent = (uint32_t)(pt ? cext : yext);
+			d.dextent = dg.out8 ? (uint32_t)(pt ? crows * dg.cstride : (uint64_t)part_h * dg.stride) : d.extent;
+			d.fpitch = pt ? cpitch : ypitch;
+			d.dfpitch = dg.out8 ? (pt ? dg.cpitch : dg.ypitch) : d.fpitch;
+			d.rowbytes = nblk * bw * sz;
+			d.drowbytes = dg.out8 ? nblk * bw : d.rowbytes;
+			d.nrows = pt ? (int)((part_y + part_h + suby - 1) / suby) - (int)((part_y + suby - 1) / suby) : (int)part_h;
+			int shift_samples = 0, lanes = 0;
+			vfgs::lane_layout(8 + s.bs, (int)bw, (int)nblk, &shift_samples, &lanes);
+			d.segs = (lanes + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
+			d.upt = (lanes + d.segs - 1) / d.segs;
+			if (d.upt & 1) d.upt++;                     // even: the lanes of a pair (and their roles) stay together in every segment
+			d.tiles = (d.segs + vfgs::kSegsPerTile - 1) / vfgs::kSegsPerTile;
+			d.tiles_w = 1;
+			while (d.tiles_w < d.tiles && d.tiles_w < vfgs::kWavesPerWG) d.tiles_w *= 2;
+			d.colgroups = (d.tiles + d.tiles_w - 1) / d.tiles_w;
+			const int phases = vfgs::kWavesPerWG / d.tiles_w;
+			d.ppb = std::min<int>(phases, std::max<int>(1, (int)rpb / rows_per_wave));
+			d.bpw = phases / d.ppb;
+			d.splits = std::max<int>(1, (int)rpb / (d.ppb * rows_per_wave));
+			auto lg = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
+			d.ltiles_w = lg(d.tiles_w); d.lppb = lg(d.ppb); d.lsplits = lg(d.splits);
+			const int nbgroups = (nbr_stripe + d.bpw - 1) / d.bpw;
+			d.wgs = d.nrows > 0 ? nbgroups * d.splits * d.colgroups : 0;
+			waves += (long)(pt ? 2 : 1) * d.wgs * vfgs::kWavesPerWG * nframes;
+		}
+		if (pass == 0)
+		{
+			const long slots = (long)s.cu_count * 16;          // wave slots of the chip at this kernel's occupancy
+			int r = rows_per_wave;
+			while (r > 1 && waves * rows_per_wave / r < VFGS_MIN_ROUNDS * slots) r /= 2;
+			if (r == rows_per_wave) break;
+			rows_per_wave = r;
+		}
 	}
 
 	// seeds: every frame of the batch runs the full state machine; frame 0's part gives the offsets
@@ -765,13 +820,12 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		hi = std::max(hi, p.cur0 + (uint64_t)nbr_stripe * nblk);
 		hi = std::max(hi, p.up0 + nblk);
 	}
-	// Images are uploaded on the stream of the call that needs them first; every use of an image slot (upload or kernel)
-	// is chained behind the previous one by the slot's event, so a call on ANOTHER stream starts after the upload, and a
-	// slot is only overwritten after all its readers (StreamCache::use_begin / use_end, DevRing likewise).
+	// Images are uploaded on the stream of the call that needs them first; a call on ANOTHER stream waits (once) for that
+	// upload, and a slot is only overwritten after all its readers (SlotGuard)
 	if (int e = upload_tables(s, stream)) return e;
 	if (int e = upload_stream(s, lo, hi, stream)) return e;
-	HIP_TRY(s.tables_ring.use_begin(stream));
-	HIP_TRY(s.lfsr.use_begin(stream));
+	HIP_TRY(s.tables_ring.use(stream));
+	HIP_TRY(s.lfsr.use(stream));
 	a.tables = (const uint8_t*)s.tables_ring.current();
 	a.stream = s.lfsr.dev();
 	a.stream_bytes = (uint32_t)(s.lfsr.dev_words() * 4);
@@ -784,8 +838,6 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	if (per_frame > 0x7fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;
 	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, (int)per_frame, stream));
-	HIP_TRY(s.tables_ring.use_end(stream));
-	HIP_TRY(s.lfsr.use_end(stream));
 	return 0;
 }
 

@@ -377,9 +377,9 @@ __device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, uint32_t v
 	__builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, VFGS_STAUX);
 }
 
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8>
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, int IMG_BYTES>
 __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, int r,
-                                          const uint32_t img_off, const uint32_t img_bytes, const uint32_t bank_off, const int lane, const int wave)
+                                          const uint32_t img_off, const uint32_t bank_off, const int lane, const int wave)
 {
 	constexpr int NS = DEPTH == 8 ? 16 : 8;
 	constexpr int SZ = DEPTH > 8 ? 2 : 1;
@@ -536,10 +536,27 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 #pragma unroll
 		for (int g = 0; g < 4; g++) load_seg(frs, vo[g], rowb, w[g]);
 	}
-	// stage this plane type's LUTs + bank: global (L2 resident) -> LDS
+	// stage this plane type's LUTs + bank: global (L2 resident) -> LDS.  All loads are issued before the first write:
+	// a load -> wait -> write loop costs one L2 round trip per 16 bytes per thread (9 of them for the luma image), and a
+	// workgroup lives for only a few dozen microseconds
 #if VFGS_ABLATE != 2
-	for (uint32_t i = threadIdx.x * 16; i < img_bytes; i += kWavesPerWG * 64 * 16)
-		*(u32x4*)(lds + i) = *(const u32x4*)(a.tables + img_off + i);
+	{
+		constexpr int STEP = kWavesPerWG * 64 * 16;
+		constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
+		u32x4 tmp[NIT];
+#pragma unroll
+		for (int it = 0; it < NIT; it++)
+		{
+			const uint32_t i = threadIdx.x * 16 + it * STEP;
+			if (it + 1 < NIT || i < (uint32_t)IMG_BYTES) tmp[it] = *(const u32x4*)(a.tables + img_off + i);
+		}
+#pragma unroll
+		for (int it = 0; it < NIT; it++)
+		{
+			const uint32_t i = threadIdx.x * 16 + it * STEP;
+			if (it + 1 < NIT || i < (uint32_t)IMG_BYTES) *(u32x4*)(lds + i) = tmp[it];
+		}
+	}
 #endif
 	__syncthreads();
 	if (k0 >= k1)
@@ -658,13 +675,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3
 	const int f = blockIdx.y;            // grid: x = workgroup inside the frame, y = frame of the batch
 	int r = blockIdx.x;
 	if (r < a.pd[0].wgs)
-		run_plane<DEPTH, 16, 1, 1, L::LRS, OUT8>(a, a.pd[0], lds, 0, f, r, L::Y_OFF, L::Y_BYTES, L::Y_BANK, lane, wave);
+		run_plane<DEPTH, 16, 1, 1, L::LRS, OUT8, L::Y_BYTES>(a, a.pd[0], lds, 0, f, r, L::Y_OFF, L::Y_BANK, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
 		const int comp = 1 + (r >= a.pd[1].wgs);
 		if (comp == 2) r -= a.pd[1].wgs;
-		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L::CRS, OUT8>(a, a.pd[1], lds, comp, f, r, L::C_OFF, L::C_BYTES, L::C_BANK, lane, wave);
+		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L::CRS, OUT8, L::C_BYTES>(a, a.pd[1], lds, comp, f, r, L::C_OFF, L::C_BANK, lane, wave);
 	}
 }
 
