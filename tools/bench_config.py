@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--preroll-ms", type=float, default=150.0)
     args = ap.parse_args()
     name, w, hh, depth, (sx, sy), trace, kernel = CONFIGS[args.config]
+    import os
+    if os.environ.get("VFGS_LIB"):
+        hw.load(os.environ["VFGS_LIB"])      # a variant build (tools/gpu_variants.sh)
     h = hw.VfgsHip(device=0)
     T.replay(h, T.load_trace(trace))
     dt = torch.int16 if depth > 8 else torch.uint8

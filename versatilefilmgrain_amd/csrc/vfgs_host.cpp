@@ -39,8 +39,8 @@ __asm__(".section .rodata\n.balign 16\n.hidden vfgs_fw_blob\n.globl vfgs_fw_blob
 #endif
 extern "C" const unsigned char vfgs_fw_blob[], vfgs_fw_blob_end[];
 
-#ifndef VFGS_MIN_ROUNDS
-#define VFGS_MIN_ROUNDS 3   // a launch should fill the chip's wave slots at least this many times (else: fewer rows per wave)
+#ifndef VFGS_MIN_FILL_PCT
+#define VFGS_MIN_FILL_PCT 25   // a launch should fill at least this share of the chip's wave slots (else: fewer rows per wave)
 #endif
 
 namespace {
@@ -756,8 +756,9 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.nframes = (int)nframes;
 	a.lo2[0] = (uint32_t)(s.ymin << s.bs) * 0x10001u; a.hi2[0] = (uint32_t)(s.ymax << s.bs) * 0x10001u;
 	a.lo2[1] = (uint32_t)(s.cmin << s.bs) * 0x10001u; a.hi2[1] = (uint32_t)(s.cmax << s.bs) * 0x10001u;
-	// Rows a wave walks (its block parameters are computed once for them): vfgs::kRowsPerWave when the launch has work for
-	// several rounds of the chip's wave slots, fewer for small launches, which need the parallelism more than the reuse.
+	// Rows a wave walks (its block parameters are computed once for them): vfgs::kRowsPerWave, fewer only for launches so
+	// small that they would leave most of the chip's wave slots empty (measured: 1080p single frames gain 14 %, anything
+	// that fills a quarter of the slots is faster with the full reuse).
 	int rows_per_wave = vfgs::kRowsPerWave;
 	for (int pass = 0; pass < 2; pass++)
 	{
@@ -801,7 +802,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		{
 			const long slots = (long)s.cu_count * 16;          // wave slots of the chip at this kernel's occupancy
 			int r = rows_per_wave;
-			while (r > 1 && waves * rows_per_wave / r < VFGS_MIN_ROUNDS * slots) r /= 2;
+			while (r > 1 && waves * rows_per_wave / r * 100 < VFGS_MIN_FILL_PCT * slots) r /= 2;
 			if (r == rows_per_wave) break;
 			rows_per_wave = r;
 		}
