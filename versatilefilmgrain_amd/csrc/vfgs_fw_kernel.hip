@@ -325,26 +325,52 @@ __global__ __launch_bounds__(256) void fw_commit_chroma(FwLaunch L)
 }
 
 // ---------------------------------------------------------------------------------------
-// Copy device-generated slots into a table image (TableLayout of vfgs_layout.h) that the host
-// has just uploaded with the host-set slots and the LUTs.
-__global__ __launch_bounds__(256) void fw_patch_tables(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma,
-                                                       int luma_off, int lrs, int chroma_off, int cw, int ch, int crs)
+// Copy device-generated slots into a device image (image_layout of vfgs_layout.h) that the host
+// has just uploaded with the host-set slots and the LUTs.  one_*: that plane type is stored in the
+// one-pattern form, holding slot slot_y / slot_cb / slot_cr only (8 = the all-zero pattern: nothing to copy).
+struct PatchArgs {
+	uint8_t* img;
+	const int8_t* bank;
+	uint32_t mask_luma, mask_chroma;
+	ImageLayout L;
+	int one_y, one_c, slot_y, slot_cb, slot_cr;
+};
+
+__global__ __launch_bounds__(256) void fw_patch_tables(const PatchArgs p)
 {
 	const int o = blockIdx.x * 256 + threadIdx.x;
+	const ImageLayout& L = p.L;
 	if (o < 64 * 64)
 	{
 		const int r = o >> 6, x = o & 63;
-		for (int k = 0; k < kSlots; k++)
-			if (mask_luma >> k & 1)
-				img[luma_off + r * lrs + x * kSlots + k] = (uint8_t)bank[(size_t)k * 4096 + o];
+		uint8_t* dst = p.img + L.y_off + L.y_bank;
+		if (p.one_y)
+		{
+			if (p.slot_y < kSlots && (p.mask_luma >> p.slot_y & 1))
+				dst[r * L.y_rs + x] = (uint8_t)p.bank[(size_t)p.slot_y * 4096 + o];
+		}
+		else
+			for (int k = 0; k < kSlots; k++)
+				if (p.mask_luma >> k & 1)
+					dst[r * L.y_rs + x * kSlots + k] = (uint8_t)p.bank[(size_t)k * 4096 + o];
 	}
-	else if (o - 4096 < cw * ch)
+	else if (o - 4096 < L.cw * L.ch)
 	{
 		const int q = o - 4096;
-		const int r = q / cw, x = q % cw;
-		for (int k = 0; k < kSlots; k++)
-			if (mask_chroma >> k & 1)
-				img[chroma_off + r * crs + x * kSlots + k] = (uint8_t)bank[(size_t)(kSlots + k) * 4096 + r * 64 + x];
+		const int r = q / L.cw, x = q % L.cw;
+		if (p.one_c)
+		{
+			for (int c = 0; c < 2; c++)
+			{
+				const int k = c ? p.slot_cr : p.slot_cb;
+				if (k < kSlots && (p.mask_chroma >> k & 1))
+					p.img[L.c_off[c] + L.c_bank + r * L.c_rs + x] = (uint8_t)p.bank[(size_t)(kSlots + k) * 4096 + r * 64 + x];
+			}
+		}
+		else
+			for (int k = 0; k < kSlots; k++)
+				if (p.mask_chroma >> k & 1)
+					p.img[L.c_off[0] + L.c_bank + r * L.c_rs + x * kSlots + k] = (uint8_t)p.bank[(size_t)(kSlots + k) * 4096 + r * 64 + x];
 	}
 }
 
@@ -365,15 +391,15 @@ hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream)
 	return hipGetLastError();
 }
 
-hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby, hipStream_t stream)
+hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby,
+                           bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, hipStream_t stream)
 {
-	const int cw = 64 / csubx, ch = 64 / csuby;
-	const int lrs = 64 * kSlots + 16, crs = cw * kSlots + 16;
-	const int n = 4096 + cw * ch;
-	// bank offsets in the device image (vfgs_layout.h TableLayout): luma image = [LUT][bank], chroma image = [LUT Cb][LUT Cr][bank]
-	const int lut_bytes = 2 * 256 * 4;
-	const int luma_off = lut_bytes, chroma_off = (lut_bytes + 64 * lrs) + 2 * lut_bytes;
-	hipLaunchKernelGGL(fw_patch_tables, dim3((n + 255) / 256), dim3(256), 0, stream, img, bank, mask_luma, mask_chroma, luma_off, lrs, chroma_off, cw, ch, crs);
+	PatchArgs p{};
+	p.img = img; p.bank = bank; p.mask_luma = mask_luma; p.mask_chroma = mask_chroma;
+	p.L = image_layout(csubx, csuby, one_y, one_c);
+	p.one_y = one_y; p.one_c = one_c; p.slot_y = slot_y; p.slot_cb = slot_cb; p.slot_cr = slot_cr;
+	const int n = 4096 + p.L.cw * p.L.ch;
+	hipLaunchKernelGGL(fw_patch_tables, dim3((n + 255) / 256), dim3(256), 0, stream, p);
 	return hipGetLastError();
 }
 

@@ -23,12 +23,13 @@
 #include "vfgs_layout.h"
 
 namespace vfgs {
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, int grid, hipStream_t stream);
-int table_bytes(int csubx, int csuby);
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int grid, hipStream_t stream);
+ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
 void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes);
 hipError_t launch_diag_stream(const void* src, void* dst, size_t bytes, int mode, int grid, int cu_count, hipStream_t stream);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
-hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby, hipStream_t stream);
+hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby,
+                           bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, hipStream_t stream);
 }
 
 // The constant tables of the grain models (oracle/dump_fw_tables.c documents origin and layout),
@@ -376,6 +377,7 @@ struct State {
 	int device = -1;
 	int cu_count = 0;
 	bool tables_dirty = true;
+	bool img_one_y = false, img_one_c = false;   // form of the current table image (vfgs_layout.h: one-pattern form)
 	DevRing tables_ring;
 	// staging for the host-pointer entry points
 	void* stage[3] = {nullptr, nullptr, nullptr};
@@ -587,29 +589,47 @@ int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
 	return 0;
 }
 
-// Build the device image of vfgs_layout.h (two sub-images: luma LUT + bank, chroma LUTs + bank) from the mirror.
-template <int CSUBX, int CSUBY>
-void build_tables(const State& s, uint8_t* img)
+// The slot a component's pattern LUT selects for EVERY intensity (0..8), or -1 if it depends on the intensity.
+int uniform_slot(const uint8_t (&plut)[256])
 {
-	using L = vfgs::TableLayout<CSUBX, CSUBY>;
-	memset(img, 0, L::BYTES);
-	uint8_t* yimg = img + L::Y_OFF;
-	uint8_t* cimg = img + L::C_OFF;
+	const int k = plut[0] >> 4;
+	for (int i = 1; i < 256; i++)
+		if ((plut[i] >> 4) != k) return -1;
+	return k;
+}
+
+// Build the device image of vfgs_layout.h (luma sub-image, chroma sub-image(s); general or one-pattern form) from the mirror.
+void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool one_y, bool one_c, const int (&slot)[3])
+{
+	memset(img, 0, L.bytes);
+	// banks
+	uint8_t* yb = img + L.y_off + L.y_bank;
 	for (int r = 0; r < 64; r++)
 		for (int x = 0; x < 64; x++)
-			for (int k = 0; k < vfgs::kSlots; k++)
-				yimg[L::Y_BANK + r * L::LRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[0][k][r][x];
-	for (int r = 0; r < L::CH; r++)
-		for (int x = 0; x < L::CW; x++)
-			for (int k = 0; k < vfgs::kSlots; k++)
-				cimg[L::C_BANK + r * L::CRS + x * vfgs::kSlots + k] = (uint8_t)s.bank[1][k][r][x];
+		{
+			if (one_y) yb[r * L.y_rs + x] = slot[0] < vfgs::kSlots ? (uint8_t)s.bank[0][slot[0]][r][x] : 0;
+			else
+				for (int k = 0; k < vfgs::kSlots; k++) yb[r * L.y_rs + x * vfgs::kSlots + k] = (uint8_t)s.bank[0][k][r][x];
+		}
+	for (int c = 0; c < (one_c ? 2 : 1); c++)
+	{
+		uint8_t* cb = img + L.c_off[c] + L.c_bank;
+		for (int r = 0; r < L.ch; r++)
+			for (int x = 0; x < L.cw; x++)
+			{
+				if (one_c) cb[r * L.c_rs + x] = slot[1 + c] < vfgs::kSlots ? (uint8_t)s.bank[1][slot[1 + c]][r][x] : 0;
+				else
+					for (int k = 0; k < vfgs::kSlots; k++) cb[r * L.c_rs + x * vfgs::kSlots + k] = (uint8_t)s.bank[1][k][r][x];
+			}
+	}
+	// LUTs
 	for (int c = 0; c < 3; c++)
 	{
-		uint32_t* lut = (uint32_t*)(c == 0 ? yimg : cimg + (c - 1) * L::LUT_BYTES);
+		uint32_t* lut = (uint32_t*)(c == 0 ? img + L.y_off : img + L.c_off[c - 1] + L.c_lut[c - 1]);
 		for (int i = 0; i < 256; i++)
 		{
-			const int slot = s.plut[c][i] >> 4;   // vfgs_hw.c:212
-			const uint32_t sel = slot < vfgs::kSlots ? (uint32_t)slot : 0x0cu;  // slot 8: the reference's all-zero bank
+			const int sl = s.plut[c][i] >> 4;   // vfgs_hw.c:212
+			const uint32_t sel = sl < vfgs::kSlots ? (uint32_t)sl : 0x0cu;  // slot 8: the reference's all-zero bank
 			// scale pre-shifted so that (scale' * P + 2^15) >> 16 == round(scale * P, scale_shift) (vfgs_hw.c:263):
 			// the kernel reads the result's high half instead of shifting; <= 255 << 10 fits the 24-bit field
 			const int sc = s.slut[c][i] << (16 - s.scale_shift);
@@ -628,29 +648,34 @@ int check_luts(const State& s)
 	return 0;
 }
 
-int upload_tables(State& s, hipStream_t stream)
+// want_general: the caller needs the general (slot-interleaved) form even where one pattern would do (fused 8-bit output)
+int upload_tables(State& s, hipStream_t stream, bool want_general)
 {
-	if (!s.tables_dirty && s.tables_ring.current())
-		return 0;
 	if (int e = check_luts(s)) return e;
+	const int slot[3] = {uniform_slot(s.plut[0]), uniform_slot(s.plut[1]), uniform_slot(s.plut[2])};
+#ifdef VFGS_NO_ONE_PATTERN      // tools/gpu_variants.sh: always the general form
+	want_general = true;
+#endif
+	const bool one_y = !want_general && slot[0] >= 0, one_c = !want_general && slot[1] >= 0 && slot[2] >= 0;
+	if (!s.tables_dirty && s.tables_ring.current() && one_y == s.img_one_y && one_c == s.img_one_c)
+		return 0;
 	if (int e = fw_flush(s, stream)) return e;
 	void* dst = nullptr;
-	const int bytes = vfgs::table_bytes(s.csubx, s.csuby);
+	const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, one_y, one_c);
 	uint8_t* img = nullptr;
-	HIP_TRY(s.tables_ring.next(bytes, &dst, &img));
-	if (s.csubx == 2 && s.csuby == 2) build_tables<2, 2>(s, img);
-	else if (s.csubx == 2 && s.csuby == 1) build_tables<2, 1>(s, img);
-	else if (s.csubx == 1 && s.csuby == 1) build_tables<1, 1>(s, img);
-	else build_tables<1, 2>(s, img);
-	HIP_TRY(hipMemcpyAsync(dst, img, bytes, hipMemcpyHostToDevice, stream));
+	HIP_TRY(s.tables_ring.next(L.bytes, &dst, &img));
+	build_tables(s, img, L, one_y, one_c, slot);
+	HIP_TRY(hipMemcpyAsync(dst, img, L.bytes, hipMemcpyHostToDevice, stream));
 	if (s.dev_origin[0] | s.dev_origin[1])
 	{
 		// device-generated slots never visit the host: copy them bank -> image on the device
 		if (int e = fw_bank_stream(s, stream)) return e;
-		HIP_TRY(vfgs::launch_fw_patch((uint8_t*)dst, s.dev_bank, s.dev_origin[0], s.dev_origin[1], s.csubx, s.csuby, stream));
+		HIP_TRY(vfgs::launch_fw_patch((uint8_t*)dst, s.dev_bank, s.dev_origin[0], s.dev_origin[1], s.csubx, s.csuby, one_y, one_c,
+		                              slot[0], slot[1], slot[2], stream));
 	}
 	HIP_TRY(s.tables_ring.uploaded(stream));
 	s.tables_dirty = false;
+	s.img_one_y = one_y; s.img_one_c = one_c;
 	return 0;
 }
 
@@ -823,7 +848,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	}
 	// Images are uploaded on the stream of the call that needs them first; a call on ANOTHER stream waits (once) for that
 	// upload, and a slot is only overwritten after all its readers (SlotGuard)
-	if (int e = upload_tables(s, stream)) return e;
+	if (int e = upload_tables(s, stream, dg.out8)) return e;
 	if (int e = upload_stream(s, lo, hi, stream)) return e;
 	HIP_TRY(s.tables_ring.use(stream));
 	HIP_TRY(s.lfsr.use(stream));
@@ -838,7 +863,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
 	if (per_frame > 0x7fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, (int)per_frame, stream));
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, (int)per_frame, stream));
 	return 0;
 }
 

@@ -152,7 +152,7 @@ struct RunParam {
 // vfgs_hw.c:99-138 with the component as wave-uniform data: the x field is 10 bits at `sx`, the
 // y field the low 10 bits of the register rotated right by `sy` (component 1 takes bits 31:24
 // and 1:0 -- exactly a rotation by 24), the sign bit at `sb`.  Returns the LDS address; sign in *neg.
-template <int SUBX, int SUBY, int RS>
+template <int SUBX, int SUBY, int RS, bool ONE>
 __device__ __forceinline__ uint32_t block_param(uint32_t v, uint32_t bank_off, int sx, int sy, int sb, bool* neg)
 {
 	const uint32_t fx = (v >> sx) & 0x3ff;
@@ -160,7 +160,7 @@ __device__ __forceinline__ uint32_t block_param(uint32_t v, uint32_t bank_off, i
 	const uint32_t ox = (__umul24(fx, 13u) >> 10) * (4 / SUBX);
 	const uint32_t oy = (__umul24(fy, 12u) >> 10) * (4 / SUBY);
 	*neg = (v >> sb) & 1;
-	return __umul24(oy, (uint32_t)RS) + ox * kSlots + bank_off;
+	return __umul24(oy, (uint32_t)RS) + ox * (ONE ? 1 : kSlots) + bank_off;     // bytes per sample position: 1 or one per slot
 }
 
 // ---------------------------------------------------------------------------------------
@@ -181,7 +181,7 @@ __device__ __forceinline__ uint32_t block_param(uint32_t v, uint32_t bank_off, i
 //   F = (l1 + 3 l0 + r0 + 2) >> 2 on true values becomes, in the P~ domain of the lane whose
 //   sample is filtered,  F~ = (a~ + 3 b~ + rel * c~ + (s > 0 ? 2 : 1)) >> 2  with rel = s * s'
 //   the relative sign of the two blocks: for s = -1, -((-A + 2) >> 2) == (A + 1) >> 2.
-template <int DEPTH, int BW, bool OVERLAP>
+template <int DEPTH, int BW, bool OVERLAP, bool ONE, bool ALIGN2>
 __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
                                             const RunParam<LaneMap<DEPTH == 8 ? 16 : 8, BW>::NR>& rp,
                                             const RunParam<LaneMap<DEPTH == 8 ? 16 : 8, BW>::NR>& up,
@@ -238,18 +238,42 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 #endif
 	}
 
-	// pattern fetch: 4 samples x 8 slots = 32 bytes per quad
+	// pattern fetch.  General form: 4 samples x 8 slots = 32 bytes per quad, the sample's slot picked by v_perm_b32.
+	// One-pattern form: 4 samples = one dword (at a 2-byte aligned address where the block offsets are multiples of 2
+	// samples, ALIGN2: cut out of two aligned dwords), each value sign-extended out of its byte.
+	auto fetch4 = [&](uint32_t adq, int q, int (&out)[4]) {
+		if (ONE)
+		{
+			uint32_t d;
+			if (ALIGN2)
+			{
+				const uint32_t a4 = adq + M::col(q);
+				const uint32_t lo = *(const uint32_t*)(lds + (a4 & ~3u)), hi = *(const uint32_t*)(lds + (a4 & ~3u) + 4);
+				d = __builtin_amdgcn_alignbit(hi, lo, (a4 & 2u) * 8);
+			}
+			else
+				d = *(const uint32_t*)(lds + adq + M::col(q));
+#pragma unroll
+			for (int i = 0; i < 4; i++) out[i] = (int)(d << (24 - 8 * i)) >> 24;
+		}
+		else
+		{
+#if VFGS_ABLATE == 9
+			const u32x4 c0 = {adq, adq * 3, adq * 5, adq * 7}, c1 = {adq ^ 77, adq + 99, adq * 9, adq * 11};
+#else
+			const u32x4 c0 = *(const u32x4*)(lds + adq + M::col(q) * kSlots), c1 = *(const u32x4*)(lds + adq + M::col(q) * kSlots + 16);
+#endif
+			out[0] = pick_slot(c0.y, c0.x, e[4 * q + 0]); out[1] = pick_slot(c0.w, c0.z, e[4 * q + 1]);
+			out[2] = pick_slot(c1.y, c1.x, e[4 * q + 2]); out[3] = pick_slot(c1.w, c1.z, e[4 * q + 3]);
+		}
+	};
 #pragma unroll
 	for (int q = 0; q < NQ; q++)
 	{
-		const uint32_t adq = ad[M::run(q)];
-#if VFGS_ABLATE == 9
-		const u32x4 c0 = {adq, adq * 3, adq * 5, adq * 7}, c1 = {adq ^ 77, adq + 99, adq * 9, adq * 11};
-#else
-		const u32x4 c0 = *(const u32x4*)(lds + adq + M::col(q) * kSlots), c1 = *(const u32x4*)(lds + adq + M::col(q) * kSlots + 16);
-#endif
-		P[4 * q + 0] = pick_slot(c0.y, c0.x, e[4 * q + 0]); P[4 * q + 1] = pick_slot(c0.w, c0.z, e[4 * q + 1]);
-		P[4 * q + 2] = pick_slot(c1.y, c1.x, e[4 * q + 2]); P[4 * q + 3] = pick_slot(c1.w, c1.z, e[4 * q + 3]);
+		int v4[4];
+		fetch4(ad[M::run(q)], q, v4);
+#pragma unroll
+		for (int i = 0; i < 4; i++) P[4 * q + i] = v4[i];
 	}
 	if (OVERLAP)
 	{
@@ -258,16 +282,13 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		{
 			const int r = M::run(q);
 			const uint32_t uad = (up.pa[r] & 0xffffu) + uprowoff;
-			const u32x4 c0 = *(const u32x4*)(lds + uad + M::col(q) * kSlots), c1 = *(const u32x4*)(lds + uad + M::col(q) * kSlots + 16);
+			int Q[4];
+			fetch4(uad, q, Q);
 			const int m = (wcur ^ sg[r]) - sg[r];                            // sign_cur * weight_cur
 			const int usg = (int)up.pa[r] >> 31;
 			const int n = (wup ^ usg) - usg;                                 // sign_up * weight_up
-			const int Q0 = pick_slot(c0.y, c0.x, e[4 * q + 0]), Q1 = pick_slot(c0.w, c0.z, e[4 * q + 1]);
-			const int Q2 = pick_slot(c1.y, c1.x, e[4 * q + 2]), Q3 = pick_slot(c1.w, c1.z, e[4 * q + 3]);
-			P[4 * q + 0] = mad_vvv(Q0, n, mad_vvv(P[4 * q + 0], m, 16)) >> 5;
-			P[4 * q + 1] = mad_vvv(Q1, n, mad_vvv(P[4 * q + 1], m, 16)) >> 5;
-			P[4 * q + 2] = mad_vvv(Q2, n, mad_vvv(P[4 * q + 2], m, 16)) >> 5;
-			P[4 * q + 3] = mad_vvv(Q3, n, mad_vvv(P[4 * q + 3], m, 16)) >> 5;
+#pragma unroll
+			for (int i = 0; i < 4; i++) P[4 * q + i] = mad_vvv(Q[i], n, mad_vvv(P[4 * q + i], m, 16)) >> 5;
 		}
 	}
 
@@ -377,9 +398,9 @@ __device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, uint32_t v
 	__builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, VFGS_STAUX);
 }
 
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, int IMG_BYTES>
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, int IMG_BYTES, bool ONE>
 __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, int r,
-                                          const uint32_t img_off, const uint32_t bank_off, const int lane, const int wave)
+                                          const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
 {
 	constexpr int NS = DEPTH == 8 ? 16 : 8;
 	constexpr int SZ = DEPTH > 8 ? 2 : 1;
@@ -566,9 +587,9 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	const int fsx = comp == 0 ? 0 : (comp == 1 ? 10 : 20);
 	const int fsy = comp == 0 ? 14 : (comp == 1 ? 24 : 4);
 	const int fsb = comp == 0 ? 31 : (comp == 1 ? 2 : 15);
-	const uint32_t lutb = (comp == 2 ? 2048u : 0u) * 0x10001u;
+	const uint32_t lutb = lut_off * 0x10001u;
 	const uint32_t lo2 = a.lo2[pt], hi2 = a.hi2[pt];
-	const uint32_t pairoff = M::PAIR ? (first ? 0u : 8u * kSlots) : 0u;
+	const uint32_t pairoff = M::PAIR ? (first ? 0u : 8u * (ONE ? 1 : kSlots)) : 0u;
 	RunParam<NR> rp[4];
 #pragma unroll
 	for (int g = 0; g < 4; g++)
@@ -577,7 +598,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 		{
 			const uint32_t v = __builtin_amdgcn_alignbit(wcur[g][rr].y, wcur[g][rr].x, (cur_bit + (uint32_t)blk[g][rr]) & 31);
 			bool neg;
-			const uint32_t ad = block_param<SUBX, SUBY, RS>(v, bank_off, fsx, fsy, fsb, &neg) + pairoff;
+			const uint32_t ad = block_param<SUBX, SUBY, RS, ONE>(v, bank_off, fsx, fsy, fsb, &neg) + pairoff;
 			rp[g].pa[rr] = ad | (neg ? 0x80000000u : 0u);
 		}
 
@@ -599,7 +620,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 #endif
 			uint32_t t[4] = {w[g][0], w[g][1], w[g][2], w[g][3]};
 			if (PARTIAL && anypart[g]) rotate_partial(g, t);
-			grain_unit<DEPTH, BW, OV>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
+			grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
 			if (OUT8)
 			{
 				uint32_t n[4];
@@ -643,7 +664,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 			{
 				const uint32_t v = __builtin_amdgcn_alignbit(wup[g][rr].y, wup[g][rr].x, (up_bit + (uint32_t)blk[g][rr]) & 31);
 				bool neg;
-				const uint32_t ad = block_param<SUBX, SUBY, RS>(v, bank_off, fsx, fsy, fsb, &neg) + pairoff;
+				const uint32_t ad = block_param<SUBX, SUBY, RS, ONE>(v, bank_off, fsx, fsy, fsb, &neg) + pairoff;
 				up[g].pa[rr] = ad | (neg ? 0x80000000u : 0u);
 			}
 		for (; k < k1; k++)
@@ -661,11 +682,11 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	}
 }
 
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC>
 __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4) void grain_kernel(const KernelArgs a)
 {
-	using L = TableLayout<CSUBX, CSUBY>;
-	__shared__ __attribute__((aligned(16))) uint8_t lds[L::LDS_BYTES];
+	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
+	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes];
 
 	const int lane = threadIdx.x & 63;
 	// wave-uniform by construction; telling the compiler keeps the decoding, row offsets and buffer
@@ -675,45 +696,48 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3
 	const int f = blockIdx.y;            // grid: x = workgroup inside the frame, y = frame of the batch
 	int r = blockIdx.x;
 	if (r < a.pd[0].wgs)
-		run_plane<DEPTH, 16, 1, 1, L::LRS, OUT8, L::Y_BYTES>(a, a.pd[0], lds, 0, f, r, L::Y_OFF, L::Y_BANK, lane, wave);
+		run_plane<DEPTH, 16, 1, 1, L.y_rs, OUT8, L.y_bytes, ONEY>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
 		const int comp = 1 + (r >= a.pd[1].wgs);
 		if (comp == 2) r -= a.pd[1].wgs;
-		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L::CRS, OUT8, L::C_BYTES>(a, a.pd[1], lds, comp, f, r, L::C_OFF, L::C_BANK, lane, wave);
+		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, OUT8, L.c_bytes, ONEC>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 	}
 }
 
 // ---------------------------------------------------------------------------------------
 // host-side launcher (called from vfgs_host.cpp)
 
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC>
 static hipError_t launch_t(const KernelArgs& a, int grid, hipStream_t stream)
 {
-	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY, OUT8>), dim3(grid, a.nframes), dim3(kWavesPerWG * 64), 0, stream, a);
+	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC>), dim3(grid, a.nframes), dim3(kWavesPerWG * 64), 0, stream, a);
 	return hipGetLastError();
 }
 
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, int grid, hipStream_t stream)
+template <int DEPTH, int CSUBX, int CSUBY>
+static hipError_t launch_one(const KernelArgs& a, bool out8, bool oney, bool onec, int grid, hipStream_t stream)
 {
-#define VFGS_CASE(D, X, Y) if (depth == D && csubx == X && csuby == Y && !out8) return launch_t<D, X, Y, false>(a, grid, stream)
+	if (DEPTH == 10 && out8) return launch_t<10, CSUBX, CSUBY, true, false, false>(a, grid, stream);    // fused 8-bit output: general form only
+	if (oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, false, true, true>(a, grid, stream);
+	if (oney) return launch_t<DEPTH, CSUBX, CSUBY, false, true, false>(a, grid, stream);
+	if (onec) return launch_t<DEPTH, CSUBX, CSUBY, false, false, true>(a, grid, stream);
+	return launch_t<DEPTH, CSUBX, CSUBY, false, false, false>(a, grid, stream);
+}
+
+// oney / onec: the image holds the one-pattern form for luma / chroma (vfgs_layout.h); never with out8
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int grid, hipStream_t stream)
+{
+	if (out8 && (depth != 10 || oney || onec)) return hipErrorInvalidValue;
+#define VFGS_CASE(D, X, Y) if (depth == D && csubx == X && csuby == Y) return launch_one<D, X, Y>(a, out8, oney, onec, grid, stream)
 	VFGS_CASE(10, 2, 2); VFGS_CASE(10, 2, 1); VFGS_CASE(10, 1, 1); VFGS_CASE(10, 1, 2);
 	VFGS_CASE(8, 2, 2);  VFGS_CASE(8, 2, 1);  VFGS_CASE(8, 1, 1);  VFGS_CASE(8, 1, 2);
 #undef VFGS_CASE
-#define VFGS_CASE8(X, Y) if (depth == 10 && csubx == X && csuby == Y && out8) return launch_t<10, X, Y, true>(a, grid, stream)
-	VFGS_CASE8(2, 2); VFGS_CASE8(2, 1); VFGS_CASE8(1, 1); VFGS_CASE8(1, 2);
-#undef VFGS_CASE8
 	return hipErrorInvalidValue;
 }
 
-int table_bytes(int csubx, int csuby)
-{
-	if (csubx == 2 && csuby == 2) return TableLayout<2, 2>::BYTES;
-	if (csubx == 2 && csuby == 1) return TableLayout<2, 1>::BYTES;
-	if (csubx == 1 && csuby == 1) return TableLayout<1, 1>::BYTES;
-	return TableLayout<1, 2>::BYTES;
-}
+ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec) { return image_layout(csubx, csuby, oney, onec); }
 
 // the plane type's lane layout, for the host's geometry: samples per lane, samples the unit grid is shifted, lanes per row
 void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes)

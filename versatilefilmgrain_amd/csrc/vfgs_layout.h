@@ -42,17 +42,21 @@ constexpr int kBlock = 16;       // luma samples per grain block
 constexpr int kWavesPerWG = VFGS_WAVES;
 constexpr int kRowsPerWave = VFGS_ROWS_PER_WAVE;
 
-// Device image of everything the kernel looks up: two sub-images, one per plane type; a workgroup
-// (which works on ONE plane) copies the sub-image of its plane type to LDS offset 0.
+// Device image of everything the kernel looks up: one sub-image per plane type (luma; chroma) -- or per chroma
+// component -- and a workgroup (which works on ONE plane) copies the sub-image of its plane to LDS offset 0.
 //
-//   luma image  : [LUT Y : 2 x 256 dwords] [luma bank  : 64 rows x LRS bytes]
-//   chroma image: [LUT Cb: 2 x 256 dwords] [LUT Cr: 2 x 256 dwords] [chroma bank: CH rows x CRS bytes]
+//   luma image  : [LUT Y : 2 x 256 dwords] [luma bank]
+//   chroma image: [LUT Cb: 2 x 256 dwords] [LUT Cr: 2 x 256 dwords] [chroma bank]                 (general form)
+//             or: [LUT Cb] [bank of Cb's pattern]   and   [LUT Cr] [bank of Cr's pattern]          (one-pattern form)
 //
-// Pattern banks are stored "slot-interleaved": for every (row, column) position the eight slots'
-// int8 values sit in 8 consecutive bytes, so the LDS address of a sample's pattern data does NOT
-// depend on the sample's intensity (the slot is picked afterwards in registers with v_perm_b32);
-// four samples are two ds_read_b128.  Each bank row is padded by one 16-byte slot so consecutive
-// rows rotate through the sixteen 16-byte LDS slots of a 256-byte bank row.
+// GENERAL form of a bank ("slot-interleaved"): for every (row, column) position the eight slots' int8 values sit in 8
+// consecutive bytes, so the LDS address of a sample's pattern data does NOT depend on the sample's intensity (the slot
+// is picked afterwards in registers with v_perm_b32); four samples are two ds_read_b128.  Each bank row is padded by one
+// 16-byte slot so consecutive rows rotate through the sixteen 16-byte LDS slots of a 256-byte bank row.
+//
+// ONE-PATTERN form: when a component's pattern LUT selects the same slot for every intensity (all AFGS1 models, the
+// single-pattern SEI models, the chroma of the default SEI model) only that pattern is stored, one byte per sample, rows
+// padded by 16 bytes; four samples are one dword.  An eighth of the LDS traffic and of the LDS footprint.
 //
 // LUT (one dword per 8-bit intensity; per component TWO tables of 256 entries, the first with
 // +scale, the second with -scale, so that a block's random sign is applied by choosing the table
@@ -60,27 +64,41 @@ constexpr int kRowsPerWave = VFGS_ROWS_PER_WAVE;
 // 2048 bytes below 64 KiB: the LDS address of a sample's entry is (4 * intensity) | base | sign << 10,
 // two samples per v_and_or_b32.  Entry:
 //   bits 31:24 byte selector for v_perm_b32: slot 0..7, or 0x0c (constant zero) for slot 8
-//              (the reference's never-written 9th slot, vfgs_hw.c:49)
+//              (the reference's never-written 9th slot, vfgs_hw.c:49); unused in the one-pattern form
 //   bits 23:0  signed scale factor (+-sLUT), pre-shifted: scale << (16 - scale_shift)
-template <int CSUBX, int CSUBY>
-struct TableLayout {
-	static constexpr int LRS = 64 * kSlots + 16;        // luma bank row stride, bytes
-	static constexpr int CW = 64 / CSUBX;               // chroma bank columns actually addressable
-	static constexpr int CH = 64 / CSUBY;               // chroma bank rows
-	static constexpr int CRS = CW * kSlots + 16;        // chroma bank row stride, bytes
-	static constexpr int LUT_BYTES = 2 * 256 * 4;       // one component: +scale table, -scale table
-	// offsets inside a sub-image (= LDS offsets)
-	static constexpr int Y_BANK = LUT_BYTES;
-	static constexpr int C_BANK = 2 * LUT_BYTES;
-	static constexpr int Y_BYTES = Y_BANK + 64 * LRS;
-	static constexpr int C_BYTES = C_BANK + CH * CRS;
-	// offsets of the sub-images in the device image
-	static constexpr int Y_OFF = 0;
-	static constexpr int C_OFF = Y_BYTES;
-	static constexpr int BYTES = Y_BYTES + C_BYTES;
-	static constexpr int LDS_BYTES = Y_BYTES > C_BYTES ? Y_BYTES : C_BYTES;
-	static_assert(Y_BYTES % 16 == 0 && C_BYTES % 16 == 0, "sub-images are copied in 16-byte pieces");
+struct ImageLayout {
+	int lut_bytes;              // one component: +scale table, -scale table
+	int y_rs, c_rs;             // bank row strides, bytes
+	int y_bank, c_bank;         // offsets of the banks inside their sub-images (= LDS offsets)
+	int y_bytes, c_bytes;       // sizes of the sub-images (chroma: of ONE chroma sub-image)
+	int y_off, c_off[2];        // offsets of the sub-images of Y, Cb, Cr in the device image
+	int c_lut[2];               // LDS offset of Cb's / Cr's LUT pair inside its sub-image
+	int bytes;                  // whole device image
+	int lds_bytes;              // LDS a workgroup needs
+	int cw, ch;                 // chroma bank columns actually addressable, rows
 };
+
+constexpr ImageLayout image_layout(int csubx, int csuby, bool one_y, bool one_c)
+{
+	ImageLayout L{};
+	L.lut_bytes = 2 * 256 * 4;
+	L.cw = 64 / csubx;
+	L.ch = 64 / csuby;
+	L.y_rs = one_y ? 64 + 16 : 64 * kSlots + 16;
+	L.c_rs = one_c ? L.cw + 16 : L.cw * kSlots + 16;
+	L.y_bank = L.lut_bytes;
+	L.c_bank = one_c ? L.lut_bytes : 2 * L.lut_bytes;
+	L.y_bytes = L.y_bank + 64 * L.y_rs;
+	L.c_bytes = L.c_bank + L.ch * L.c_rs;
+	L.y_off = 0;
+	L.c_off[0] = L.y_bytes;
+	L.c_off[1] = one_c ? L.y_bytes + L.c_bytes : L.y_bytes;
+	L.c_lut[0] = 0;
+	L.c_lut[1] = one_c ? 0 : L.lut_bytes;
+	L.bytes = L.y_bytes + (one_c ? 2 : 1) * L.c_bytes;
+	L.lds_bytes = L.y_bytes > L.c_bytes ? L.y_bytes : L.c_bytes;
+	return L;
+}
 
 // Geometry of one plane type (0 = luma, 1 = the two chroma planes) for one launch.
 //
@@ -113,7 +131,7 @@ struct KernelArgs {
 	PlaneDesc pd[2];
 	const uint32_t* stream;   // LFSR bit stream cache (device), bit m = word[m>>5] >> (m&31)
 	uint32_t stream_bytes;
-	const uint8_t* tables;    // TableLayout image (device)
+	const uint8_t* tables;    // device image (image_layout)
 	uint32_t cur_bit0;        // stream bit of the register of block 0, first block row of the stripe, frame 0
 	uint32_t up_bit0;         // same for the "upper" register of that first block row
 	uint32_t frame_bit_step;  // stream bits between consecutive frames of a batch
