@@ -21,10 +21,12 @@
 //     once and reused for every row; while a segment is being computed the same registers of the
 //     segment after next are already being refilled ("rolling prefetch": the registers of a
 //     segment are reloaded with the next row right after its store);
-//   * a WORKGROUP of 8 waves covers all tiles of a few consecutive rows (full rows, contiguous in
+//   * a WORKGROUP of 4 waves covers all tiles of a few consecutive rows (full rows, contiguous in
 //     memory), is NOT persistent and copies only its plane's banks + LUTs to LDS; workgroups are
 //     numbered in memory order, so the chip sweeps the frames front to back with a compact window
-//     and the hardware dispatcher balances the load.
+//     and the hardware dispatcher balances the load;
+//   * a component whose pattern LUT selects one slot for every intensity is served from a packed
+//     one-byte-per-sample bank (ONEY / ONEC kernels, vfgs_layout.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -69,28 +71,6 @@ __device__ __forceinline__ int mad_vvv(int x, int y, int c)
 {
 	int r;
 	asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(c));
-	return r;
-}
-
-// The edge filter's per-block constants travel in ONE register: byte 0 = rounding constant of run 0, byte 1 = that of
-// run 1, high half = relative sign of the two blocks at the edge (+1 / -1).  They are consumed in place:
-// x + packed.byte[N] (SDWA operand select) and packed.hi16 * y + c (op_sel): no unpacking instructions.
-__device__ __forceinline__ int add_byte0(int x, uint32_t packed)
-{
-	int r;
-	asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(packed));
-	return r;
-}
-__device__ __forceinline__ int add_byte1(int x, uint32_t packed)
-{
-	int r;
-	asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(packed));
-	return r;
-}
-__device__ __forceinline__ int mad_hi16(uint32_t packed, int y, int c)
-{
-	int r;   // packed.i16[1] * y.i16[0] + c   (|y| <= 143 here)
-	asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(packed), "v"(y), "v"(c));
 	return r;
 }
 
@@ -682,8 +662,13 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	}
 }
 
+// 8-bit planes with 8-sample blocks hold three block runs and two edges per lane (LaneMap): those kernels get the
+// registers of one workgroup less per CU instead of spilling in the row loop
+template <int DEPTH, int CSUBX>
+constexpr int wg_per_cu() { return (DEPTH == 8 && CSUBX == 2 && VFGS_WG_PER_CU > VFGS_WG_PER_CU_8BIT_SUB) ? VFGS_WG_PER_CU_8BIT_SUB : VFGS_WG_PER_CU; }
+
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC>
-__global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4) void grain_kernel(const KernelArgs a)
+__global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * wg_per_cu<DEPTH, CSUBX>() + 3) / 4) void grain_kernel(const KernelArgs a)
 {
 	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes];

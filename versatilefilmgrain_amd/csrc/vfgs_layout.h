@@ -20,6 +20,9 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_WG_PER_CU
 #define VFGS_WG_PER_CU 4  // resident workgroups per CU the register allocation is sized for
 #endif
+#ifndef VFGS_WG_PER_CU_8BIT_SUB
+#define VFGS_WG_PER_CU_8BIT_SUB 3   // ... for the 8-bit kernels with horizontally subsampled chroma (three block runs per lane)
+#endif
 #ifndef VFGS_LDAUX
 #define VFGS_LDAUX 0      // cache policy bits of the sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
