@@ -167,7 +167,8 @@ int vfgs_hip_timer_end(void* stream, float* elapsed_ms);
 /* Diagnostics for benchmarks (no grain arithmetic, never called by the library itself): stream `bytes` bytes
  * once through the chip -- mode 0: out-of-place copy src -> dst (16 bytes per lane); mode 1: in-place
  * read-modify-write of dst, persistent waves that move 4 KiB per step (`grid` workgroups of 4 waves, 0 = 8 per CU);
- * mode 2: the same with one workgroup per 16 KiB.  Pointers and size: multiples of 16.  bench.py times these in
+ * mode 2: the same with one workgroup per 16 KiB; mode 3: mode 2 with nontemporal loads and stores (the fastest stream
+ * found on gfx950; needs line-aligned wave accesses).  Pointers and size: multiples of 16.  bench.py times these in
  * its own process, on its own buffers, at the grain launch's size, as the copy ceiling of the chip. */
 int vfgs_hip_diag_stream(const void* src, void* dst, uint64_t bytes, int mode, int grid, void* stream);
 

@@ -86,6 +86,112 @@ __global__ void k_flat_rmw(u32x4* __restrict__ buf, size_t n)
 	}
 }
 
+
+// non-persistent in-place variants: KB KiB per wave (1 KiB per access), optional XCD-contiguous remap and cache policy
+template <int KB, int REMAP, int LDAUX, int STAUX>
+__global__ void k_flat_rmw_np2(uint8_t* __restrict__ buf, size_t nbytes)
+{
+	size_t wg = blockIdx.x;
+	if (REMAP) { const size_t per = gridDim.x / 8; wg = (blockIdx.x % 8) * per + blockIdx.x / 8; if (blockIdx.x >= per * 8) wg = blockIdx.x; }
+	const size_t wave = wg * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	const size_t base = wave * (size_t)KB * 1024;
+	if (base + (size_t)KB * 1024 > nbytes) return;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + base), 0, KB * 1024, 0x00020000);
+	u32x4 v[KB];
+#pragma unroll
+	for (int u = 0; u < KB; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, 0, LDAUX);
+#pragma unroll
+	for (int u = 0; u < KB; u++) __builtin_amdgcn_raw_buffer_store_b128(v[u] + 1u, rs, (u * 64 + lane) * 16, 0, STAUX);
+}
+
+
+// np2 with the grain kernel's occupancy and row walk: LDSKB KiB of LDS per workgroup (36 -> 4 workgroups = 16 waves per CU),
+// optional staging of that LDS from a table, ROWS consecutive 4 KiB tiles per wave (stride = the workgroup's 16 KiB) with the
+// registers of an access refilled right after its store
+template <int LDSKB, int STAGE, int ROWS, int LDAUX, int STAUX, int MODE = 0>
+__global__ __launch_bounds__(256) void k_flat_rmw_np4(uint8_t* __restrict__ buf, size_t nbytes, const uint8_t* tables)
+{
+	// MODE 0: store + refill per access; 1: per row load all, store all; 2: all rows loaded up front; 3: as 0, the wave's rows contiguous
+	__shared__ __attribute__((aligned(16))) uint8_t lds[LDSKB * 1024 + 16];
+	if (STAGE) { for (int i = threadIdx.x * 16; i < LDSKB * 1024; i += 256 * 16) *(u32x4*)(lds + i) = *(const u32x4*)(tables + i); __syncthreads(); }
+	else if (LDSKB) lds[threadIdx.x] = 1;
+	const int lane = threadIdx.x & 63;
+	const uint32_t rstride = MODE == 3 ? 4096 : 16384;
+	const size_t base = MODE == 3 ? ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS * 4096 : ((size_t)blockIdx.x * ROWS * 4 + (threadIdx.x >> 6)) * 4096;
+	if ((size_t)(blockIdx.x + 1) * ROWS * 16384 > nbytes) return;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + base), 0, ROWS * 16384, 0x00020000);
+	if (MODE == 2)
+	{
+		u32x4 w[ROWS][4];
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+#pragma unroll
+			for (int u = 0; u < 4; u++) w[r][u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16 + r * rstride, 0, LDAUX);
+#pragma unroll
+		for (int r = 0; r < ROWS; r++)
+#pragma unroll
+			for (int u = 0; u < 4; u++) __builtin_amdgcn_raw_buffer_store_b128(w[r][u] + (uint32_t)lds[LDSKB ? (w[r][u].x & 1023) : 0], rs, (u * 64 + lane) * 16 + r * rstride, 0, STAUX);
+		return;
+	}
+	u32x4 v[4];
+	if (MODE == 1)
+	{
+		for (int r = 0; r < ROWS; r++)
+		{
+#pragma unroll
+			for (int u = 0; u < 4; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, r * rstride, LDAUX);
+#pragma unroll
+			for (int u = 0; u < 4; u++) __builtin_amdgcn_raw_buffer_store_b128(v[u] + (uint32_t)lds[LDSKB ? (v[u].x & 1023) : 0], rs, (u * 64 + lane) * 16, r * rstride, STAUX);
+		}
+		return;
+	}
+#pragma unroll
+	for (int u = 0; u < 4; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, 0, LDAUX);
+	for (int r = 0; r < ROWS; r++)
+	{
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			__builtin_amdgcn_raw_buffer_store_b128(v[u] + (uint32_t)lds[LDSKB ? (v[u].x & 1023) : 0], rs, (u * 64 + lane) * 16, r * rstride, STAUX);
+			v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, r + 1 < ROWS ? (uint32_t)((u * 64 + lane) * 16) : kOOB, (r + 1) * rstride, LDAUX);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+}
+
+// the same with every access shifted by SHIFT bytes (what the grain kernel's half-block shift does to its 1 KiB accesses),
+// UPT lanes per access (the grain kernel: 62), and optionally only the 4 KiB tile shifted while its accesses stay aligned:
+// TILEMODE 1: aligned 1 KiB accesses, the tile's first 16 bytes are not stored and the 16 bytes behind it are moved by one lane
+template <int SHIFT, int UPT, int TILEMODE, int LDAUX, int STAUX>
+__global__ void k_flat_rmw_np3(uint8_t* __restrict__ buf, size_t nbytes)
+{
+	const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	const size_t tile = (size_t)UPT * 16 * 4;
+	const size_t base = wave * tile;
+	if (base + tile + 64 > nbytes || base < 64) return;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + base), 0, (uint32_t)tile + 32, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + base - 64), 0, (uint32_t)tile + 128, 0x00020000);
+	u32x4 v[4], x;
+	if (TILEMODE == 0)
+	{
+#pragma unroll
+		for (int u = 0; u < 4; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs2, lane < UPT ? (uint32_t)(64 - SHIFT + (u * UPT + lane) * 16) : kOOB, 0, LDAUX);
+#pragma unroll
+		for (int u = 0; u < 4; u++) __builtin_amdgcn_raw_buffer_store_b128(v[u] + 1u, rs2, lane < UPT ? (uint32_t)(64 - SHIFT + (u * UPT + lane) * 16) : kOOB, 0, STAUX);
+	}
+	else
+	{
+#pragma unroll
+		for (int u = 0; u < 4; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)((u * 64 + lane) * 16), 0, LDAUX);
+		x = __builtin_amdgcn_raw_buffer_load_b128(rs, lane == 0 ? (uint32_t)tile : kOOB, 0, LDAUX);
+#pragma unroll
+		for (int u = 0; u < 4; u++) __builtin_amdgcn_raw_buffer_store_b128(v[u] + 1u, rs, (u == 0 && lane == 0) ? kOOB : (uint32_t)((u * 64 + lane) * 16), 0, STAUX);
+		__builtin_amdgcn_raw_buffer_store_b128(x + 1u, rs, lane == 0 ? (uint32_t)tile : kOOB, 0, STAUX);
+	}
+}
+
 // ---- round-1 structure -----------------------------------------------------------------------
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_rowitem(const Geo g, const uint8_t* tables)
@@ -564,43 +670,27 @@ int main(int argc, char** argv)
 	struct Variant { std::string name; std::function<void(int)> launch; std::vector<float> t; };
 	std::vector<Variant> vs;
 	const size_t n16 = set / 16;
-	vs.push_back({"flat_copy out-of-place 2048x256", [&](int s) { k_flat_copy<<<2048, 256>>>((const u32x4*)pool[s], (u32x4*)alt, n16); }, {}});
-	vs.push_back({"flat_copy out-of-place 4096x256", [&](int s) { k_flat_copy<<<4096, 256>>>((const u32x4*)pool[s], (u32x4*)alt, n16); }, {}});
-	vs.push_back({"flat_rmw x4 in-place 1024x256", [&](int s) { k_flat_rmw<4><<<1024, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw x4 in-place 1536x256", [&](int s) { k_flat_rmw<4><<<1536, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw x4 in-place 2048x256", [&](int s) { k_flat_rmw<4><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw x2 in-place 2048x256", [&](int s) { k_flat_rmw<2><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw x1 in-place 2048x256", [&](int s) { k_flat_rmw<1><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw x4 in-place 3072x256", [&](int s) { k_flat_rmw<4><<<3072, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw x4 in-place 4096x256", [&](int s) { k_flat_rmw<4><<<4096, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw x4 in-place 512x1024", [&](int s) { k_flat_rmw<4><<<512, 1024>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw x8 in-place 2048x256", [&](int s) { k_flat_rmw<8><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw non-persistent x4", [&](int s) { k_flat_rmw_np<<<(unsigned)(n16 / 256 / 4), 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw_pf x4 2048x256", [&](int s) { k_flat_rmw_pf<4><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw_pf x4 1024x256", [&](int s) { k_flat_rmw_pf<4><<<1024, 256>>>((u32x4*)pool[s], n16); }, {}});
-	vs.push_back({"flat_rmw_pf x2 2048x256", [&](int s) { k_flat_rmw_pf<2><<<2048, 256>>>((u32x4*)pool[s], n16); }, {}});
-	const long nitems_total = (long)(4320 * 4 + 2 * 2160 * 2) * NF;
-	unsigned* counter;
-	CK(hipMalloc(&counter, 4));
-	for (int work : {0, 12})
-	{
-		const int extra_item = work ? 36 : 0;
-		char nm[128];
-#define ADD(NAME, ...) snprintf(nm, sizeof nm, NAME " work %d extra %d", work, extra_item); vs.push_back({nm, [&, work, extra_item](int s) { __VA_ARGS__; }, {}})
-#define NPGRID(WAVES, STEPS) (unsigned)((nitems_total + (WAVES) * (STEPS) - 1) / ((WAVES) * (STEPS)))
-		ADD("rowitem 12w x2/CU", k_rowitem<12><<<cus * 2, 768>>>(geo(s, work, extra_item), tables));
-		ADD("rowitem NP 8w steps 4", k_rowitem_np<8, 0><<<NPGRID(8, 4), 512>>>(geo(s, work, extra_item), tables, 4));
-		ADD("rowitem NP+PF 8w steps 4", k_rowitem_np<8, 1><<<NPGRID(8, 4), 512>>>(geo(s, work, extra_item), tables, 4));
-		ADD("rowitem NP+PF 4w steps 4", k_rowitem_np<4, 1><<<NPGRID(4, 4), 256>>>(geo(s, work, extra_item), tables, 4));
-		ADD("rowitem DYN 8w x3/CU steps 4", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<8><<<cus * 3, 512>>>(geo(s, work, extra_item), tables, 4, counter));
-		ADD("rowitem DYN 8w x3/CU steps 2", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<8><<<cus * 3, 512>>>(geo(s, work, extra_item), tables, 2, counter));
-		ADD("rowitem DYN 8w x3/CU steps 1", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<8><<<cus * 3, 512>>>(geo(s, work, extra_item), tables, 1, counter));
-		ADD("rowitem DYN 4w x4/CU steps 4", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<4><<<cus * 4, 256>>>(geo(s, work, extra_item), tables, 4, counter));
-		ADD("rowitem DYN 4w x4/CU steps 2", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<4><<<cus * 4, 256>>>(geo(s, work, extra_item), tables, 2, counter));
-		ADD("rowitem DYN 4w x6/CU steps 4", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<4><<<cus * 6, 256>>>(geo(s, work, extra_item), tables, 4, counter));
-		ADD("rowitem DYN 12w x2/CU steps 2", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<12><<<cus * 2, 768>>>(geo(s, work, extra_item), tables, 2, counter));
-		ADD("rowitem DYN 16w x2/CU steps 1", hipMemsetAsync(counter, 0, 4); k_rowitem_dyn<16><<<cus * 2, 1024>>>(geo(s, work, extra_item), tables, 1, counter));
-	}
+	const size_t set_b = set;
+#define NP2(NAME, KB, REMAP, LA, SA, THREADS) vs.push_back({NAME, [&](int s) { k_flat_rmw_np2<KB, REMAP, LA, SA><<<(unsigned)(set_b / ((size_t)KB * 1024 * (THREADS / 64))), THREADS>>>(pool[s], set_b); }, {}})
+#define NP3(NAME, SHIFT, UPT, TM, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_np3<SHIFT, UPT, TM, LA, SA><<<(unsigned)(set_b / ((size_t)UPT * 64 * 4)), 256>>>(pool[s], set_b); }, {}})
+#define NP4(NAME, LDSKB, STAGE, ROWS, LA, SA, MODE) vs.push_back({NAME, [&](int s) { k_flat_rmw_np4<LDSKB, STAGE, ROWS, LA, SA, MODE><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b, tables); }, {}})
+	NP4("np4 36K LDS rows 1 both nt", 36, 0, 1, 2, 2, 0);
+	NP4("np4 36K LDS rows 2 rolling both nt", 36, 0, 2, 2, 2, 0);
+	NP4("np4 36K LDS rows 4 rolling both nt", 36, 0, 4, 2, 2, 0);
+	NP4("np4 36K LDS rows 4 load4/store4 both nt", 36, 0, 4, 2, 2, 1);
+	NP4("np4 36K LDS rows 4 loads up front both nt", 36, 0, 4, 2, 2, 2);
+	NP4("np4 36K LDS rows 2 loads up front both nt", 36, 0, 2, 2, 2, 2);
+	NP4("np4 36K LDS rows 4 rolling contiguous both nt", 36, 0, 4, 2, 2, 3);
+	NP4("np4 36K LDS rows 4 rolling plain", 36, 0, 4, 0, 0, 0);
+	NP4("np4 36K LDS rows 4 load4/store4 plain", 36, 0, 4, 0, 0, 1);
+	NP4("np4 36K LDS rows 4 rolling nt stores only", 36, 0, 4, 0, 2, 0);
+	NP4("np4 36K LDS staged rows 1 both nt", 36, 1, 1, 2, 2, 0);
+	NP2("np2 4KiB/wave aligned plain", 4, 0, 0, 0, 256);
+	NP2("np2 4KiB/wave aligned both nt", 4, 0, 2, 2, 256);
+	NP2("np2 4KiB/wave aligned both nt XCD-contig", 4, 1, 2, 2, 256);
+	NP3("np3 tile-shift aligned accesses plain", 0, 64, 1, 0, 0);
+	NP3("np3 tile-shift aligned accesses both nt", 0, 64, 1, 2, 2);
+	NP3("np3 tile-shift aligned accesses nt loads", 0, 64, 1, 2, 0);
 
 	const int rounds = argc > 1 ? atoi(argv[1]) : 5, reps = 6;
 	for (int r = 0; r <= rounds; r++)

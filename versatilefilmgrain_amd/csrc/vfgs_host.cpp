@@ -809,6 +809,9 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 			d.segs = (lanes + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
 			d.upt = (lanes + d.segs - 1) / d.segs;
 			if (d.upt & 1) d.upt++;                     // even: the lanes of a pair (and their roles) stay together in every segment
+#ifdef VFGS_ALIGN_TEST
+			d.upt = vfgs::kMaxUnits;
+#endif
 			d.tiles = (d.segs + vfgs::kSegsPerTile - 1) / vfgs::kSegsPerTile;
 			d.tiles_w = 1;
 			while (d.tiles_w < d.tiles && d.tiles_w < vfgs::kWavesPerWG) d.tiles_w *= 2;
@@ -1449,7 +1452,7 @@ int vfgs_hip_diag_stream(const void* src, void* dst, uint64_t bytes, int mode, i
 	std::lock_guard<std::mutex> g(g_mu);
 	if (int e = ensure_init(-1)) return e;
 	if (((uintptr_t)src | (uintptr_t)dst | bytes) & 15) return fail(7, "vfgs_hip_diag_stream: pointers and size must be multiples of 16 bytes");
-	if (mode < 0 || mode > 2 || !dst || (mode == 0 && !src)) return fail(25, "vfgs_hip_diag_stream: mode %d", mode);
+	if (mode < 0 || mode > 3 || !dst || (mode == 0 && !src)) return fail(25, "vfgs_hip_diag_stream: mode %d", mode);
 	HIP_TRY(vfgs::launch_diag_stream(src, dst, (size_t)bytes, mode, grid, S().cu_count, (hipStream_t)stream));
 	return 0;
 }

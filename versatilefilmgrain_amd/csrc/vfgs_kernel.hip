@@ -438,7 +438,11 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 		const int seg = tile * kSegsPerTile + g;
 		const int p = seg * pd.upt + lane;                                 // lane position along the row
 		const bool sok = (seg < pd.segs) && (lane < pd.upt);
+#ifdef VFGS_ALIGN_TEST   // timing only (tools/gpu_variants.sh, with VFGS_ABLATE=1): line-aligned accesses, wrong results
+		const int x = p * 16;
+#else
 		const int x = p * 16 - M::SHIFT * SZ;                              // first byte of the lane in the row
+#endif
 		const bool full = sok && x >= 0 && x + 16 <= (int)pd.rowbytes;
 		const bool part = PARTIAL && sok && !full && x + 16 > 0 && x < (int)pd.rowbytes;
 		fullm[g] = full;

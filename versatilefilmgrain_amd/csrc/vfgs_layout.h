@@ -41,6 +41,8 @@ constexpr int kBlock = 16;       // luma samples per grain block
                           //   3 copy only + no LFSR loads, 4 copy only + partly valid lanes ignored,
                           //   5 no stores, 8 no LUT gather, 9 no pattern fetch
 #endif
+// VFGS_ALIGN_TEST (undefined in the product): timing-only, WRONG output: 64 lanes per segment and no half-block shift, so
+// every wave access is a line-aligned 1 KiB (what the nontemporal policies need; DESIGN.md 4 "nontemporal accesses").
 
 constexpr int kWavesPerWG = VFGS_WAVES;
 constexpr int kRowsPerWave = VFGS_ROWS_PER_WAVE;
