@@ -160,6 +160,52 @@ __global__ __launch_bounds__(256) void k_flat_rmw_np4(uint8_t* __restrict__ buf,
 	}
 }
 
+// window test: as np4 MODE 0, but row r of workgroup g is the 16 KiB chunk r * gridDim.x + g: at any time the chip works on
+// one dense window of the buffer although every wave lives for ROWS chunks (what a persistent grid-stride kernel does)
+template <int LDSKB, int ROWS, int LDAUX, int STAUX>
+__global__ __launch_bounds__(256) void k_flat_rmw_np5(uint8_t* __restrict__ buf, size_t nbytes)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[LDSKB * 1024 + 16];
+	if (LDSKB) lds[threadIdx.x] = 1;
+	const int lane = threadIdx.x & 63;
+	const size_t rstride = (size_t)gridDim.x * 16384;
+	const uint8_t* b0 = buf + (size_t)blockIdx.x * 16384 + (threadIdx.x >> 6) * 4096;
+	if (rstride * ROWS > nbytes) return;
+	u32x4 v[4];
+	__amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)b0, 0, 4096, 0x00020000);
+#pragma unroll
+	for (int u = 0; u < 4; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, 0, LDAUX);
+	for (int r = 0; r < ROWS; r++)
+	{
+		const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)(b0 + (r + 1) * rstride), 0, r + 1 < ROWS ? 4096 : 0, 0x00020000);
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			__builtin_amdgcn_raw_buffer_store_b128(v[u] + (uint32_t)lds[LDSKB ? (v[u].x & 1023) : 0], rs, (u * 64 + lane) * 16, 0, STAUX);
+			v[u] = __builtin_amdgcn_raw_buffer_load_b128(rn, (u * 64 + lane) * 16, 0, LDAUX);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		rs = rn;
+	}
+}
+
+template <int UNROLL, int LDAUX, int STAUX>
+__global__ void k_flat_rmw_pers_nt(uint8_t* __restrict__ buf, size_t nbytes)
+{
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	const int lane = threadIdx.x & 63;
+	for (size_t base = wave * 1024 * UNROLL; base + 1024 * UNROLL <= nbytes; base += nwaves * 1024 * UNROLL)
+	{
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + base), 0, 1024 * UNROLL, 0x00020000);
+		u32x4 v[UNROLL];
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, 0, LDAUX);
+#pragma unroll
+		for (int u = 0; u < UNROLL; u++) __builtin_amdgcn_raw_buffer_store_b128(v[u] + 1u, rs, (u * 64 + lane) * 16, 0, STAUX);
+	}
+}
+
 // the same with every access shifted by SHIFT bytes (what the grain kernel's half-block shift does to its 1 KiB accesses),
 // UPT lanes per access (the grain kernel: 62), and optionally only the 4 KiB tile shifted while its accesses stay aligned:
 // TILEMODE 1: aligned 1 KiB accesses, the tile's first 16 bytes are not stored and the 16 bytes behind it are moved by one lane
@@ -674,17 +720,18 @@ int main(int argc, char** argv)
 #define NP2(NAME, KB, REMAP, LA, SA, THREADS) vs.push_back({NAME, [&](int s) { k_flat_rmw_np2<KB, REMAP, LA, SA><<<(unsigned)(set_b / ((size_t)KB * 1024 * (THREADS / 64))), THREADS>>>(pool[s], set_b); }, {}})
 #define NP3(NAME, SHIFT, UPT, TM, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_np3<SHIFT, UPT, TM, LA, SA><<<(unsigned)(set_b / ((size_t)UPT * 64 * 4)), 256>>>(pool[s], set_b); }, {}})
 #define NP4(NAME, LDSKB, STAGE, ROWS, LA, SA, MODE) vs.push_back({NAME, [&](int s) { k_flat_rmw_np4<LDSKB, STAGE, ROWS, LA, SA, MODE><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b, tables); }, {}})
+#define NP5(NAME, LDSKB, ROWS, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_np5<LDSKB, ROWS, LA, SA><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b); }, {}})
+#define PNT(NAME, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_pers_nt<4, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b); }, {}})
 	NP4("np4 36K LDS rows 1 both nt", 36, 0, 1, 2, 2, 0);
-	NP4("np4 36K LDS rows 2 rolling both nt", 36, 0, 2, 2, 2, 0);
 	NP4("np4 36K LDS rows 4 rolling both nt", 36, 0, 4, 2, 2, 0);
-	NP4("np4 36K LDS rows 4 load4/store4 both nt", 36, 0, 4, 2, 2, 1);
-	NP4("np4 36K LDS rows 4 loads up front both nt", 36, 0, 4, 2, 2, 2);
-	NP4("np4 36K LDS rows 2 loads up front both nt", 36, 0, 2, 2, 2, 2);
-	NP4("np4 36K LDS rows 4 rolling contiguous both nt", 36, 0, 4, 2, 2, 3);
-	NP4("np4 36K LDS rows 4 rolling plain", 36, 0, 4, 0, 0, 0);
-	NP4("np4 36K LDS rows 4 load4/store4 plain", 36, 0, 4, 0, 0, 1);
-	NP4("np4 36K LDS rows 4 rolling nt stores only", 36, 0, 4, 0, 2, 0);
-	NP4("np4 36K LDS staged rows 1 both nt", 36, 1, 1, 2, 2, 0);
+	NP5("np5 36K LDS rows 4 dense window both nt", 36, 4, 2, 2);
+	NP5("np5 36K LDS rows 16 dense window both nt", 36, 16, 2, 2);
+	NP5("np5 36K LDS rows 64 dense window both nt", 36, 64, 2, 2);
+	NP5("np5 36K LDS rows 4 dense window plain", 36, 4, 0, 0);
+	NP5("np5 36K LDS rows 16 dense window plain", 36, 16, 0, 0);
+	PNT("persistent grid-stride 4 wg/cu both nt", 4, 2, 2);
+	PNT("persistent grid-stride 8 wg/cu both nt", 8, 2, 2);
+	PNT("persistent grid-stride 8 wg/cu plain", 8, 0, 0);
 	NP2("np2 4KiB/wave aligned plain", 4, 0, 0, 0, 256);
 	NP2("np2 4KiB/wave aligned both nt", 4, 0, 2, 2, 256);
 	NP2("np2 4KiB/wave aligned both nt XCD-contig", 4, 1, 2, 2, 256);

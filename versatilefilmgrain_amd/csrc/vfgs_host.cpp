@@ -23,7 +23,8 @@
 #include "vfgs_layout.h"
 
 namespace vfgs {
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int grid, hipStream_t stream);
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool aligned, int grid, hipStream_t stream);
+bool aligned_ok(int depth, int csubx, int nblk, bool out8);
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
 void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes);
 hipError_t launch_diag_stream(const void* src, void* dst, size_t bytes, int mode, int grid, int cu_count, hipStream_t stream);
@@ -785,6 +786,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	// small that they would leave most of the chip's wave slots empty (measured: 1080p single frames gain 14 %, anything
 	// that fills a quarter of the slots is faster with the full reuse).
 	int rows_per_wave = vfgs::kRowsPerWave;
+	const bool aligned = vfgs::aligned_ok(8 + s.bs, (int)s.csubx, (int)nblk, dg.out8);
 	for (int pass = 0; pass < 2; pass++)
 	{
 		long waves = 0;
@@ -809,9 +811,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 			d.segs = (lanes + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
 			d.upt = (lanes + d.segs - 1) / d.segs;
 			if (d.upt & 1) d.upt++;                     // even: the lanes of a pair (and their roles) stay together in every segment
-#ifdef VFGS_ALIGN_TEST
-			d.upt = vfgs::kMaxUnits;
-#endif
+			if (aligned) d.upt = vfgs::kMaxUnits;       // whole aligned units: segment = 1 KiB of the row (the lanes compute bytes shifted against it)
 			d.tiles = (d.segs + vfgs::kSegsPerTile - 1) / vfgs::kSegsPerTile;
 			d.tiles_w = 1;
 			while (d.tiles_w < d.tiles && d.tiles_w < vfgs::kWavesPerWG) d.tiles_w *= 2;
@@ -866,7 +866,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
 	if (per_frame > 0x7fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, (int)per_frame, stream));
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, aligned, (int)per_frame, stream));
 	return 0;
 }
 

@@ -38,6 +38,7 @@ namespace vfgs {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
@@ -363,22 +364,57 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 // not depend on where those lanes are -- which is what lets the compiler count outstanding refills (a
 // wave-uniform branch around a memory instruction makes it wait for everything instead).
 
+template <int AUX = VFGS_LDAUX>
 __device__ __forceinline__ void load_seg(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, uint32_t (&w)[4])
 {
-	const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, VFGS_LDAUX);
+	const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
 	w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
 }
 
+// A buffer store of more than 64 bits reads its data registers AFTER it has issued; a VALU write to them in the next
+// cycle changes what the last lanes (12..15 of every 16) store.  The compiler's hazard recognizer inserts the wait state
+// only for stores WITHOUT a scalar offset register (the documented form of the hazard); on gfx950 the stores with one
+// need it too (found the hard way: DESIGN.md 4 "store data hazard").  Two wait states after every such store.
+__device__ __forceinline__ void store_data_hazard()
+{
+	__builtin_amdgcn_sched_barrier(0);     // nothing may move between the store and the wait states
+	asm volatile("s_nop 1");
+	__builtin_amdgcn_sched_barrier(0);
+}
+
+template <int AUX = VFGS_STAUX>
 __device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, const uint32_t (&w)[4])
 {
 #if VFGS_ABLATE == 5   // (almost) never store: keeps the math alive, drops the write traffic
 	if (!(w[0] == 0x12345678u && w[3] == 0x9abcdef0u)) return;
 #endif
 	const u32x4 t = {w[0], w[1], w[2], w[3]};
-	__builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, VFGS_STAUX);
+	__builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, AUX);
+	store_data_hazard();
 }
 
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, int IMG_BYTES, bool ONE>
+// the first / last N dwords of a unit (aligned mode: the part of a unit that belongs to the neighbouring tile's wave)
+template <int N, int AUX>
+__device__ __forceinline__ void load_dwords(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, uint32_t (&w)[4])
+{
+	if (N == 4) { const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
+	else if (N == 2) { const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX); w[0] = t.x; w[1] = t.y; }
+	else w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX);
+}
+
+template <int N, int AUX>
+__device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, const uint32_t* w)
+{
+#if VFGS_ABLATE == 5
+	if (!(w[0] == 0x12345678u)) return;
+#endif
+	if (N == 4) { const u32x4 t = {w[0], w[1], w[2], w[3]}; __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, AUX); store_data_hazard(); }
+	else if (N == 3) { const u32x3 t = {w[0], w[1], w[2]}; __builtin_amdgcn_raw_buffer_store_b96(t, rs, voff, soff, AUX); store_data_hazard(); }
+	else if (N == 2) { const u32x2 t = {w[0], w[1]}; __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, AUX); }
+	else if (N == 1) __builtin_amdgcn_raw_buffer_store_b32(w[0], rs, voff, soff, AUX);
+}
+
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, int IMG_BYTES, bool ONE, bool AL>
 __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, int r,
                                           const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
 {
@@ -388,7 +424,10 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	constexpr int NR = M::NR;
 	constexpr int RPB = 16 / SUBY;                       // rows of this plane per block row
 	constexpr int NEF = M::PAIR ? 1 : M::NE;
-	constexpr bool PARTIAL = !M::PAIR && VFGS_ABLATE != 4;   // rows of this plane type begin and end with a partly valid lane
+	constexpr bool PARTIAL = !AL && !M::PAIR && VFGS_ABLATE != 4;   // rows of this plane type begin and end with a partly valid lane
+	constexpr int K = M::SHIFT * SZ / 4;                 // aligned mode: dwords of a lane that lie in the memory unit before the lane's own
+	constexpr int LDA = AL ? VFGS_LDAUX_ALIGNED : VFGS_LDAUX, STA = AL ? VFGS_STAUX_ALIGNED : VFGS_STAUX;
+	static_assert(!(AL && OUT8), "the narrowed destination keeps the shifted accesses");
 	constexpr bool HALVES = !(NS == 16 && BW == 8);      // ... whose valid part is one 8-byte half (else: 1 or 3 dwords)
 	const int pt = comp ? 1 : 0;
 
@@ -409,11 +448,18 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	const int row_first = (a.y0 + SUBY - 1) / SUBY;      // first row of the stripe in this plane; the plane pointers address row y0 / SUBY
 	const int prow0 = a.y0 / SUBY;
 	const bool active = (tile < pd.tiles) && (kbr < a.nbrows);
-	// rows of this block row that belong to the stripe: [alo, ahi); mine: base + ppb * k, k in [k0, k1)
+	// rows of this block row that belong to the stripe: [alo, ahi); mine: base + stp * k, k in [k0, k1)
 	const int alo = max(row_first, Rabs * RPB), ahi = min(row_first + pd.nrows, (Rabs + 1) * RPB);
+#if VFGS_SPLIT_INTERLEAVE
+	// the parts of a block row are interleaved: the workgroups of one block row, dispatched back to back, sweep it together
+	const int lstp = pd.lppb + pd.lsplits, stp = 1 << lstp;
+	const int base = uni(Rabs * RPB + (split << pd.lppb) + ph);
+#else
+	const int lstp = pd.lppb, stp = pd.ppb;
 	const int base = uni(Rabs * RPB + split * (RPB >> pd.lsplits) + ph);
+#endif
 	const int nk = (RPB >> pd.lsplits) >> pd.lppb;
-	int k0 = max(0, alo - base + pd.ppb - 1) >> pd.lppb, k1 = min(nk, (max(0, ahi - base) + pd.ppb - 1) >> pd.lppb);
+	int k0 = max(0, alo - base + stp - 1) >> lstp, k1 = min(nk, (max(0, ahi - base) + stp - 1) >> lstp);
 	if (!active) k1 = k0 = 0;
 	k0 = uni(k0); k1 = uni(k1);
 
@@ -424,7 +470,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	const int last = a.nblk - 1;
 	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(kbr * a.nblk);
 	const uint32_t up_bit = (kbr > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
-	const bool any_up = (Rabs > 0) && ((base + pd.ppb * k0 - Rabs * RPB) * SUBY <= 1);   // my first row is an overlap line (vfgs_hw.c:175,180)
+	const bool any_up = (Rabs > 0) && ((base + stp * k0 - Rabs * RPB) * SUBY <= 1);   // my first row is an overlap line (vfgs_hw.c:175,180)
 
 	uint32_t vo[4];                    // byte offset inside a row of the 16 bytes the lane LOADS, or kOOB
 	bool fullm[4];                     // the lane lies completely inside the row: it stores its 16 bytes at vo
@@ -438,16 +484,13 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 		const int seg = tile * kSegsPerTile + g;
 		const int p = seg * pd.upt + lane;                                 // lane position along the row
 		const bool sok = (seg < pd.segs) && (lane < pd.upt);
-#ifdef VFGS_ALIGN_TEST   // timing only (tools/gpu_variants.sh, with VFGS_ABLATE=1): line-aligned accesses, wrong results
-		const int x = p * 16;
-#else
 		const int x = p * 16 - M::SHIFT * SZ;                              // first byte of the lane in the row
-#endif
-		const bool full = sok && x >= 0 && x + 16 <= (int)pd.rowbytes;
+		const bool full = AL ? (sok && p * 16 + 16 <= (int)pd.rowbytes) : (sok && x >= 0 && x + 16 <= (int)pd.rowbytes);
 		const bool part = PARTIAL && sok && !full && x + 16 > 0 && x < (int)pd.rowbytes;
 		fullm[g] = full;
 		anypart[g] = PARTIAL && __builtin_amdgcn_ballot_w64(part) != 0;
-		vo[g] = full ? (uint32_t)x : (part ? (uint32_t)min(max(x, 0), (int)pd.rowbytes - 16) : kOOB);
+		// aligned mode: the lane MOVES memory unit p (bytes [16p, 16p + 16) of the row) and COMPUTES bytes [x, x + 16)
+		vo[g] = full ? (uint32_t)(AL ? p * 16 : x) : (part ? (uint32_t)min(max(x, 0), (int)pd.rowbytes - 16) : kOOB);
 		if (M::PAIR)
 		{
 			const int ju = p - 1;                                          // 8-sample unit of the row
@@ -533,13 +576,20 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 			if (any_up) wup[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs, ((up_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
 #endif
 		}
-	uint32_t rowb = (uint32_t)uni((base + pd.ppb * k0 - prow0) * (int)pd.pitch), drowb = (uint32_t)uni((base + pd.ppb * k0 - prow0) * (int)pd.dpitch);
-	const uint32_t rstep = (uint32_t)pd.ppb * pd.pitch, drstep = (uint32_t)pd.ppb * pd.dpitch;
+	// aligned mode: the last K dwords of the unit before the tile are this wave's (lane 0 of segment 0 computes them), the
+	// last K dwords of the tile's last unit are the next wave's
+	uint32_t pre[4] = {0, 0, 0, 0};
+	const uint32_t preoff = (AL && lane == 0 && tile > 0 && tile * kSegsPerTile < pd.segs) ? (uint32_t)(tile * (kSegsPerTile * kMaxUnits * 16) - K * 4) : kOOB;
+	const uint32_t vos3 = (AL && lane == 63) ? kOOB : vo[3];
+	const uint32_t tailoff = (AL && lane == 63) ? vo[3] : kOOB;
+	uint32_t rowb = (uint32_t)uni((base + stp * k0 - prow0) * (int)pd.pitch), drowb = (uint32_t)uni((base + stp * k0 - prow0) * (int)pd.dpitch);
+	const uint32_t rstep = (uint32_t)stp * pd.pitch, drstep = (uint32_t)stp * pd.dpitch;
 	uint32_t w[4][4];
 	{
 		const __amdgpu_buffer_rsrc_t frs = make_rsrc(sbase, (k0 < k1) ? pd.extent : 0);
 #pragma unroll
-		for (int g = 0; g < 4; g++) load_seg(frs, vo[g], rowb, w[g]);
+		for (int g = 0; g < 4; g++) load_seg<LDA>(frs, vo[g], rowb, w[g]);
+		if (AL) load_dwords<K, LDA>(frs, preoff, rowb, pre);
 	}
 	// stage this plane type's LUTs + bank: global (L2 resident) -> LDS.  All loads are issued before the first write:
 	// a load -> wait -> write loop costs one L2 round trip per 16 bytes per thread (9 of them for the luma image), and a
@@ -591,7 +641,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	// fixed and the compiler can count the outstanding refills instead of waiting for all of them)
 	auto row = [&](auto overlap, const int k, const RunParam<NR> (&up)[4], const int wc_, const int wu_) {
 		constexpr bool OV = decltype(overlap)::value;
-		const int j = base + pd.ppb * k - Rabs * RPB;                        // row inside the block row
+		const int j = base + stp * k - Rabs * RPB;                        // row inside the block row
 		const uint32_t rowoff = (uint32_t)j * RS, uprowoff = (uint32_t)(RPB + j) * RS;
 		// the refill of the row after my last one goes through a descriptor with zero records: the hardware
 		// drops it, the instruction stream (and the compiler's vmcnt counting) stays the same
@@ -635,6 +685,75 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 		drowb += drstep;
 	};
 
+	// Aligned mode.  The memory side moves whole aligned units (line-aligned 1 KiB wave accesses, nontemporal: DESIGN.md 4);
+	// the computation keeps the half-block shifted lanes.  A lane's 4 dwords are the last K dwords of the unit of the lane
+	// BEFORE it (DPP wave_shr:1; lane 0 takes them from lane 63 of the previous segment through SGPRs, or from the unit in
+	// front of the tile) and the first 4 - K of its own; results go back the same way, so the store of a segment waits for
+	// lane 0 of the NEXT segment.  The registers of a segment are refilled as soon as the lanes have been assembled.
+	auto row_al = [&](auto overlap, const int k, const RunParam<NR> (&up)[4], const int wc_, const int wu_) {
+		constexpr bool OV = decltype(overlap)::value;
+		const int j = base + stp * k - Rabs * RPB;
+		const uint32_t rowoff = (uint32_t)j * RS, uprowoff = (uint32_t)(RPB + j) * RS;
+		const __amdgpu_buffer_rsrc_t nrs = make_rsrc(sbase, (k + 1 < k1) ? pd.extent : 0);
+		const bool is0 = lane == 0, is63 = lane == 63;
+#if VFGS_LANE_SHIFT_DPP
+		auto lane_up = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); };    // wave_shr:1
+		auto lane_down = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); };  // wave_shl:1
+#else
+		const int a_prev = ((lane - 1) & 63) * 4, a_next = ((lane + 1) & 63) * 4;
+		auto lane_up = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(a_prev, (int)v); };
+		auto lane_down = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(a_next, (int)v); };
+#endif
+		uint32_t carry[4] = {0, 0, 0, 0};      // wave-uniform: the last K dwords of lane 63 of the previous segment
+		uint32_t outp[4] = {0, 0, 0, 0};       // the previous segment's units, complete but for lane 63
+#pragma unroll
+		for (int g = 0; g < 4; g++)
+		{
+			uint32_t t[4];
+#pragma unroll
+			for (int d = 0; d < K; d++)
+			{
+				const uint32_t sh = lane_up(w[g][4 - K + d]);   // lane l <- lane l - 1
+				t[d] = is0 ? (g == 0 ? pre[d] : carry[d]) : sh;
+			}
+#pragma unroll
+			for (int d = 0; d < K; d++) carry[d] = (uint32_t)__builtin_amdgcn_readlane((int)w[g][4 - K + d], 63);
+#pragma unroll
+			for (int d = K; d < 4; d++) t[d] = w[g][d - K];
+			load_seg<LDA>(nrs, vo[g], rowb + rstep, w[g]);
+			if (g == 0) load_dwords<K, LDA>(nrs, preoff, rowb + rstep, pre);
+			grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
+			if (g == 0)
+			{
+				store_dwords<K, STA>(drs, preoff, drowb, t);               // lane 0: the tail of the unit in front of the tile
+			}
+			else
+			{
+#pragma unroll
+				for (int d = 0; d < K; d++)
+				{
+					const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)t[d], 0);
+					outp[4 - K + d] = is63 ? l0 : outp[4 - K + d];
+				}
+				store_b128<STA>(drs, vo[g - 1], drowb, outp);
+			}
+#pragma unroll
+			for (int d = K; d < 4; d++) outp[d - K] = t[d];
+#pragma unroll
+			for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(t[d]);   // lane l <- lane l + 1
+#if VFGS_SCHED_FENCE
+			__builtin_amdgcn_sched_barrier(0);
+#endif
+		}
+		store_b128<STA>(drs, vos3, drowb, outp);
+		if (K < 4) store_dwords<4 - K, STA>(drs, tailoff, drowb, outp);       // lane 63: the head of the tile's last unit
+		rowb += rstep;
+		drowb += drstep;
+	};
+	auto row_any = [&](auto overlap, const int k, const RunParam<NR> (&up)[4], const int wc_, const int wu_) {
+		if constexpr (AL) row_al(overlap, k, up, wc_, wu_); else row(overlap, k, up, wc_, wu_);
+	};
+
 	int k = k0;
 	if (any_up)
 	{
@@ -653,16 +772,16 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 			}
 		for (; k < k1; k++)
 		{
-			const int jrow = (base + pd.ppb * k - Rabs * RPB) * SUBY;
+			const int jrow = (base + stp * k - Rabs * RPB) * SUBY;
 			if (jrow > 1) break;
 			const int wc_ = jrow == 0 ? (SUBY > 1 ? 20 : 12) : 24, wu_ = jrow == 0 ? (SUBY > 1 ? 20 : 24) : 12;
-			row(std::true_type(), k, up, wc_, wu_);
+			row_any(std::true_type(), k, up, wc_, wu_);
 		}
 	}
 	{
 		RunParam<NR> none[4] = {};
 		for (; k < k1; k++)
-			row(std::false_type(), k, none, 0, 0);
+			row_any(std::false_type(), k, none, 0, 0);
 	}
 }
 
@@ -671,7 +790,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 template <int DEPTH, int CSUBX>
 constexpr int wg_per_cu() { return (DEPTH == 8 && CSUBX == 2 && VFGS_WG_PER_CU > VFGS_WG_PER_CU_8BIT_SUB) ? VFGS_WG_PER_CU_8BIT_SUB : VFGS_WG_PER_CU; }
 
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool AL>
 __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * wg_per_cu<DEPTH, CSUBX>() + 3) / 4) void grain_kernel(const KernelArgs a)
 {
 	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
@@ -685,45 +804,68 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * wg_per_cu<DEPTH, C
 	const int f = blockIdx.y;            // grid: x = workgroup inside the frame, y = frame of the batch
 	int r = blockIdx.x;
 	if (r < a.pd[0].wgs)
-		run_plane<DEPTH, 16, 1, 1, L.y_rs, OUT8, L.y_bytes, ONEY>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+		run_plane<DEPTH, 16, 1, 1, L.y_rs, OUT8, L.y_bytes, ONEY, AL>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
 		const int comp = 1 + (r >= a.pd[1].wgs);
 		if (comp == 2) r -= a.pd[1].wgs;
-		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, OUT8, L.c_bytes, ONEC>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, OUT8, L.c_bytes, ONEC, AL>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 	}
 }
 
 // ---------------------------------------------------------------------------------------
 // host-side launcher (called from vfgs_host.cpp)
 
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool AL>
 static hipError_t launch_t(const KernelArgs& a, int grid, hipStream_t stream)
 {
-	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC>), dim3(grid, a.nframes), dim3(kWavesPerWG * 64), 0, stream, a);
+	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC, AL>), dim3(grid, a.nframes), dim3(kWavesPerWG * 64), 0, stream, a);
 	return hipGetLastError();
 }
 
-template <int DEPTH, int CSUBX, int CSUBY>
-static hipError_t launch_one(const KernelArgs& a, bool out8, bool oney, bool onec, int grid, hipStream_t stream)
+// every plane type's rows are whole 16-byte units except 8-bit planes with 8-sample blocks and an odd number of blocks:
+// only those formats carry the kernels with shifted accesses next to the aligned ones
+template <int DEPTH, int CSUBX>
+constexpr bool has_shifted() { return !VFGS_ALIGNED || (DEPTH == 8 && CSUBX == 2); }
+
+template <int DEPTH, int CSUBX, int CSUBY, bool ONEY, bool ONEC>
+static hipError_t launch_al(const KernelArgs& a, bool aligned, int grid, hipStream_t stream)
 {
-	if (DEPTH == 10 && out8) return launch_t<10, CSUBX, CSUBY, true, false, false>(a, grid, stream);    // fused 8-bit output: general form only
-	if (oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, false, true, true>(a, grid, stream);
-	if (oney) return launch_t<DEPTH, CSUBX, CSUBY, false, true, false>(a, grid, stream);
-	if (onec) return launch_t<DEPTH, CSUBX, CSUBY, false, false, true>(a, grid, stream);
-	return launch_t<DEPTH, CSUBX, CSUBY, false, false, false>(a, grid, stream);
+	if constexpr (VFGS_ALIGNED != 0)
+		if (aligned) return launch_t<DEPTH, CSUBX, CSUBY, false, ONEY, ONEC, true>(a, grid, stream);
+	if constexpr (has_shifted<DEPTH, CSUBX>())
+		return launch_t<DEPTH, CSUBX, CSUBY, false, ONEY, ONEC, false>(a, grid, stream);
+	return hipErrorInvalidValue;
 }
 
-// oney / onec: the image holds the one-pattern form for luma / chroma (vfgs_layout.h); never with out8
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int grid, hipStream_t stream)
+template <int DEPTH, int CSUBX, int CSUBY>
+static hipError_t launch_one(const KernelArgs& a, bool out8, bool oney, bool onec, bool aligned, int grid, hipStream_t stream)
 {
-	if (out8 && (depth != 10 || oney || onec)) return hipErrorInvalidValue;
-#define VFGS_CASE(D, X, Y) if (depth == D && csubx == X && csuby == Y) return launch_one<D, X, Y>(a, out8, oney, onec, grid, stream)
+	if (DEPTH == 10 && out8) return launch_t<10, CSUBX, CSUBY, true, false, false, false>(a, grid, stream);    // fused 8-bit output: general form, shifted accesses
+	if (oney && onec) return launch_al<DEPTH, CSUBX, CSUBY, true, true>(a, aligned, grid, stream);
+	if (oney) return launch_al<DEPTH, CSUBX, CSUBY, true, false>(a, aligned, grid, stream);
+	if (onec) return launch_al<DEPTH, CSUBX, CSUBY, false, true>(a, aligned, grid, stream);
+	return launch_al<DEPTH, CSUBX, CSUBY, false, false>(a, aligned, grid, stream);
+}
+
+// oney / onec: the image holds the one-pattern form for luma / chroma (vfgs_layout.h); never with out8.
+// aligned: the plane descriptors were laid out for the aligned kernels (aligned_ok()).
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool aligned, int grid, hipStream_t stream)
+{
+	if (out8 && (depth != 10 || oney || onec || aligned)) return hipErrorInvalidValue;
+#define VFGS_CASE(D, X, Y) if (depth == D && csubx == X && csuby == Y) return launch_one<D, X, Y>(a, out8, oney, onec, aligned, grid, stream)
 	VFGS_CASE(10, 2, 2); VFGS_CASE(10, 2, 1); VFGS_CASE(10, 1, 1); VFGS_CASE(10, 1, 2);
 	VFGS_CASE(8, 2, 2);  VFGS_CASE(8, 2, 1);  VFGS_CASE(8, 1, 1);  VFGS_CASE(8, 1, 2);
 #undef VFGS_CASE
 	return hipErrorInvalidValue;
+}
+
+// may a launch use the aligned kernels?  (rows of both plane types are whole 16-byte units; not the narrowed destination)
+bool aligned_ok(int depth, int csubx, int nblk, bool out8)
+{
+	if (!VFGS_ALIGNED || out8) return false;
+	return !(depth == 8 && csubx == 2 && (nblk & 1));
 }
 
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec) { return image_layout(csubx, csuby, oney, onec); }

@@ -35,14 +35,28 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_SCHED_FENCE
 #define VFGS_SCHED_FENCE 1 // 1: a scheduling fence after every segment keeps its store and refill in program order
 #endif
+#ifndef VFGS_SPLIT_INTERLEAVE
+#define VFGS_SPLIT_INTERLEAVE 0   // 1: the workgroups that share a block row take every splits-th row instead of consecutive rows
+#endif
 #ifndef VFGS_ABLATE
 #define VFGS_ABLATE 0     // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py):
                           //   1 copy only (tables still staged, block parameters still computed), 2 copy only + no staging,
                           //   3 copy only + no LFSR loads, 4 copy only + partly valid lanes ignored,
                           //   5 no stores, 8 no LUT gather, 9 no pattern fetch
 #endif
-// VFGS_ALIGN_TEST (undefined in the product): timing-only, WRONG output: 64 lanes per segment and no half-block shift, so
-// every wave access is a line-aligned 1 KiB (what the nontemporal policies need; DESIGN.md 4 "nontemporal accesses").
+#ifndef VFGS_ALIGNED
+#define VFGS_ALIGNED 1        // 1: whole aligned 16-byte units are moved (1 KiB line-aligned wave accesses) and rotated by one lane in
+                              //    registers; 0: every lane loads and stores the shifted 16 bytes it computes (round 2's first form)
+#endif
+#ifndef VFGS_LANE_SHIFT_DPP
+#define VFGS_LANE_SHIFT_DPP 1  // aligned kernels: 1 = rotate by one lane with DPP wave_shr / wave_shl, 0 = with ds_bpermute_b32
+#endif
+#ifndef VFGS_LDAUX_ALIGNED
+#define VFGS_LDAUX_ALIGNED 2  // cache policies of the aligned kernels: nontemporal
+#endif
+#ifndef VFGS_STAUX_ALIGNED
+#define VFGS_STAUX_ALIGNED 2
+#endif
 
 constexpr int kWavesPerWG = VFGS_WAVES;
 constexpr int kRowsPerWave = VFGS_ROWS_PER_WAVE;
