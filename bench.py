@@ -234,7 +234,7 @@ def main():
                                   "kernel_sha16_profiled": rec.get("kernel_sha16")}
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "grain_kernel<10,2,2,false,false,true> (depth 10, 4:2:0, in place; luma general form, chroma one-pattern form)", "launch_us": round(launch_ms * 1e3, 2),
+                "kernel": "grain_kernel<10,2,2,false,false,true,true> (depth 10, 4:2:0, in place; luma general form, chroma one-pattern form, aligned nontemporal accesses)", "launch_us": round(launch_ms * 1e3, 2),
                 "algorithmic_bytes_per_launch": bytes_per_launch}
         if ceilings:
             best = max(ceilings.values())
