@@ -94,6 +94,29 @@ def test_ragged_sizes_garbage_padding_and_out_of_range(hip, name, width, height)
     assert a.equal_all(b)
 
 
+@pytest.mark.parametrize("name", ["fgs_sei_ar_test1_8_420", "fgs_sei_8_422", "fgs_sei_ff_test6_8_422"])
+@pytest.mark.parametrize("width", [208, 224, 720, 736, 2032, 2048])
+def test_8bit_subsampled_even_and_odd_block_counts(hip, name, width):
+    """8-bit planes with 8-sample blocks: rows are whole 16-byte units only for an even number of blocks per line.
+    Even counts run the aligned kernels, odd ones (208 = 13 blocks, 720 = 45, 2032 = 127) the kernels with shifted
+    accesses and partly valid lanes (vfgs_kernel.hip aligned_ok()); both against the oracle, on the device, with
+    row pitches that are multiples of 16 bytes (the device entry points' rule) but not of a cache line."""
+    from gpu_util import DevFrame, stream_ptr
+    ora, (depth, sx, sy) = program(hip, name)
+    assert depth == 8 and sx == 2
+    nblk = (width + 15) // 16
+    f = T.Frame(width, 70, depth, sx, sy, stride=nblk * 16 + 48, cstride=(nblk * 8 + 15) // 16 * 16 + 16)
+    rng = np.random.default_rng(width)
+    for p in f.planes():
+        p[...] = rng.integers(0, 256, p.shape).astype(f.dtype)
+    want = f.copy()
+    ora.add_grain_frame(want)
+    d = DevFrame(f)
+    hip.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), f.width, f.height, f.stride, f.cstride, stream_ptr())
+    assert d.download().equal_all(want)
+    assert hip.seed_state() == ora.seed_state()
+
+
 def test_stripes_equal_whole_frame(hip):
     """A frame fed as uneven host stripes (not multiples of 16) == line by line."""
     ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
