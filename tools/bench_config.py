@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--preroll-ms", type=float, default=150.0)
+    ap.add_argument("--content", choices=["uniform", "ramp"], default="uniform",
+                    help="uniform: random over the full code range (worst case for LUT / pattern divergence, SURVEY 8d); "
+                         "ramp: smooth diagonal ramp + -4..+4 noise (natural-like, reported separately)")
     args = ap.parse_args()
     name, w, hh, depth, (sx, sy), trace, kernel = CONFIGS[args.config]
     import os
@@ -50,6 +53,14 @@ def main():
     pool = min(pool, 64)
 
     def mk(rows, cols):
+        if args.content == "ramp":
+            r = torch.arange(rows, device="cuda", dtype=torch.int32).view(1, rows, 1)
+            c = torch.arange(cols, device="cuda", dtype=torch.int32).view(1, 1, cols)
+            f = torch.arange(args.batch, device="cuda", dtype=torch.int32).view(args.batch, 1, 1)
+            lo, hi = (16 << (depth - 8)), (235 << (depth - 8))
+            base = lo + ((r * 3 + c * 2 + f * 37) >> 3) % (hi - lo)
+            noise = torch.randint(-4, 5, (args.batch, rows, cols), dtype=torch.int32, device="cuda", generator=g)
+            return (base + noise).clamp(0, (1 << depth) - 1).to(dt)
         return torch.randint(0, 1 << depth, (args.batch, rows, cols), dtype=torch.int32, device="cuda", generator=g).to(dt)
     sets = [(mk(hh, w), mk(hh // sy, w // sx), mk(hh // sy, w // sx)) for _ in range(pool)]
     st = torch.cuda.current_stream().cuda_stream
@@ -73,7 +84,7 @@ def main():
     us = launch_us / args.batch
     samples = w * hh * (1 + 2 / (sx * sy))
     nbytes = 2 * sz * samples
-    print(json.dumps({"config": args.config, "workload": name, "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
+    print(json.dumps({"config": args.config, "workload": name, "content": args.content, "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
                       "launch_us": round(launch_us, 2), "us_per_frame": round(us, 3), "algorithmic_bytes_per_frame": int(nbytes),
                       "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 4),
                       "Mpixels_per_s": round(w * hh / us, 1), "Msamples_per_s": round(samples / us, 1)}), flush=True)
