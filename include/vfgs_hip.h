@@ -172,6 +172,19 @@ int vfgs_hip_timer_end(void* stream, float* elapsed_ms);
  * its own process, on its own buffers, at the grain launch's size, as the copy ceiling of the chip. */
 int vfgs_hip_diag_stream(const void* src, void* dst, uint64_t bytes, int mode, int grid, void* stream);
 
+/* SURVEY 8f row f3 -- the data path around the reference's yuv_read / yuv_write (yuv.c:162-214): nframes frames that live
+ * in HOST memory, processed in place and pipelined through a ring of three device frames: the upload of frame i, the
+ * kernel of frame i-1 and the download of frame i-2 are queued on three streams.  Y/U/V: arrays of nframes plane pointers
+ * (any host memory; frames need not be contiguous), all frames with the same geometry, strides in samples as in
+ * vfgs_add_grain_stripe.  Only the bytes the reference touches (whole 16-sample blocks of every row) travel; stride
+ * padding is never written.  Pinned memory (vfgs_hip_host_alloc) makes the copies asynchronous; with pageable memory the
+ * call is correct but the runtime stages every copy and the calling thread blocks for it.  Returns when all frames are
+ * back in host memory; the seed registers have advanced as after nframes whole-frame calls.  0 or an error code. */
+int vfgs_hip_add_grain_frames_host(void* const* Y, void* const* U, void* const* V, unsigned nframes, unsigned width,
+                                   unsigned height, unsigned stride, unsigned cstride);
+void* vfgs_hip_host_alloc(uint64_t bytes);   /* pinned host memory (hipHostMalloc); NULL on failure */
+void vfgs_hip_host_free(void* p);
+
 /* Introspection for benchmarks/tests. */
 int vfgs_hip_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* name, int name_len);
 

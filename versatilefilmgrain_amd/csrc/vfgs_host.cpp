@@ -385,6 +385,31 @@ struct State {
 	size_t stage_cap[3] = {0, 0, 0};
 	hipStream_t own_stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	// frames in host memory, pipelined (vfgs_hip_add_grain_frames_host): a ring of device frames, one stream per stage
+	struct HostPipe {
+		static constexpr int kDepth = 3;
+		hipStream_t up = nullptr, run = nullptr, down = nullptr;
+		void* dev[kDepth][3] = {};
+		size_t cap[kDepth][3] = {};
+		hipEvent_t up_done[kDepth] = {}, run_done[kDepth] = {}, down_done[kDepth] = {};
+		bool busy[kDepth] = {};
+		void release()
+		{
+			for (int k = 0; k < kDepth; k++)
+			{
+				for (int i = 0; i < 3; i++) { if (dev[k][i]) (void)hipFree(dev[k][i]); dev[k][i] = nullptr; cap[k][i] = 0; }
+				if (up_done[k]) (void)hipEventDestroy(up_done[k]);
+				if (run_done[k]) (void)hipEventDestroy(run_done[k]);
+				if (down_done[k]) (void)hipEventDestroy(down_done[k]);
+				up_done[k] = run_done[k] = down_done[k] = nullptr;
+				busy[k] = false;
+			}
+			if (up) (void)hipStreamDestroy(up);
+			if (run) (void)hipStreamDestroy(run);
+			if (down) (void)hipStreamDestroy(down);
+			up = run = down = nullptr;
+		}
+	} pipe;
 
 	// firmware layer on the device (include/vfgs_hip_fw.h): slots whose pattern was generated on
 	// the device live in dev_bank; the host mirror above holds the slots set through the setters
@@ -910,6 +935,87 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 }
 
 // ------------------------------------------------------------------------------------
+// Frames in host memory, pipelined (the data path around yuv_read / yuv_write, yuv.c:162-214).
+// Frame i is uploaded on one stream while frame i-1 runs on a second and frame i-2 is downloaded on a third; a ring of
+// three device frames, events between the stages, the caller's thread only waits when it wants a ring slot back.  Only
+// the bytes the reference touches (whole blocks of every row) travel, so stride padding in host memory is never written.
+// With pinned host memory (vfgs_hip_host_alloc) the copies are asynchronous; pageable memory works, the runtime then
+// stages every copy itself and the calling thread blocks for it.  The seed registers advance frame by frame exactly as
+// with nframes calls of the frame entry point.
+int run_host_frames(void* const* Y, void* const* U, void* const* V, unsigned nframes, unsigned width, unsigned height,
+                    unsigned stride, unsigned cstride)
+{
+	State& s = S();
+	if (int e = ensure_init(-1)) return e;
+	if (nframes == 0 || height == 0) return 0;
+	if (!Y || !U || !V) return fail(4, "vfgs_hip_add_grain_frames_host: null pointer array");
+	if (width <= 128) return fail(5, "width %u: the hardware layer requires width > 128 (vfgs_hw.c:168)", width);
+	if ((width + 15) / 16 > 1984) return fail(17, "width %u exceeds the supported 31744 samples", width);
+	if (int e = check_luts(s)) return e;     // before anything is queued
+	State::HostPipe& P = s.pipe;
+	constexpr int D = State::HostPipe::kDepth;
+	const unsigned sz = s.bs ? 2 : 1;
+	const unsigned nblk = (width + 15) / 16;
+	const unsigned crows = (height - 1) / s.csuby + 1;
+	const unsigned rows[3] = {height, crows, crows};
+	const unsigned rowlen[3] = {nblk * 16 * sz, nblk * 16 / s.csubx * sz, nblk * 16 / s.csubx * sz};
+	if ((size_t)stride * sz < rowlen[0] || (size_t)cstride * sz < rowlen[1])
+		return fail(6, "stride too small: every row must hold whole 16-sample blocks (vfgs_hw.c:301)");
+	const unsigned dpitch[3] = {(rowlen[0] + 255) & ~255u, (rowlen[1] + 255) & ~255u, (rowlen[2] + 255) & ~255u};
+	const size_t spitch[3] = {(size_t)stride * sz, (size_t)cstride * sz, (size_t)cstride * sz};
+	if (!P.up)
+	{
+		HIP_TRY(hipStreamCreateWithFlags(&P.up, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&P.run, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&P.down, hipStreamNonBlocking));
+		for (int k = 0; k < D; k++)
+		{
+			HIP_TRY(hipEventCreateWithFlags(&P.up_done[k], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&P.run_done[k], hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&P.down_done[k], hipEventDisableTiming));
+		}
+	}
+	int rc = 0;
+	for (unsigned f = 0; f < nframes && !rc; f++)
+	{
+		const int k = (int)(f % D);
+		void* host[3] = {Y[f], U[f], V[f]};
+		if (!host[0] || !host[1] || !host[2]) { rc = fail(4, "vfgs_hip_add_grain_frames_host: null plane pointer in frame %u", f); break; }
+		if (P.busy[k]) { HIP_TRY(hipEventSynchronize(P.down_done[k])); P.busy[k] = false; }   // the slot's previous frame is back in host memory
+		for (int i = 0; i < 3; i++)
+		{
+			const size_t need = (size_t)dpitch[i] * rows[i] + 256;
+			if (P.cap[k][i] < need)
+			{
+				if (P.dev[k][i]) HIP_TRY(hipFree(P.dev[k][i]));
+				P.dev[k][i] = nullptr; P.cap[k][i] = 0;
+				HIP_TRY(hipMalloc(&P.dev[k][i], need));
+				P.cap[k][i] = need;
+			}
+			HIP_TRY(hipMemcpy2DAsync(P.dev[k][i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, P.up));
+		}
+		HIP_TRY(hipEventRecord(P.up_done[k], P.up));
+		HIP_TRY(hipStreamWaitEvent(P.run, P.up_done[k], 0));
+		rc = run_device(P.dev[k][0], P.dev[k][1], P.dev[k][2], P.dev[k][0], P.dev[k][1], P.dev[k][2], width, 0, height, 0, height,
+		                dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, P.run);
+		if (rc) break;
+		HIP_TRY(hipEventRecord(P.run_done[k], P.run));
+		HIP_TRY(hipStreamWaitEvent(P.down, P.run_done[k], 0));
+		for (int i = 0; i < 3; i++)
+			HIP_TRY(hipMemcpy2DAsync(host[i], spitch[i], P.dev[k][i], dpitch[i], rowlen[i], rows[i], hipMemcpyDeviceToHost, P.down));
+		HIP_TRY(hipEventRecord(P.down_done[k], P.down));
+		P.busy[k] = true;
+	}
+	// everything queued so far comes home before the call returns, also after an error
+	(void)hipStreamSynchronize(P.up);
+	(void)hipStreamSynchronize(P.run);
+	const hipError_t e = hipStreamSynchronize(P.down);
+	for (int k = 0; k < D; k++) P.busy[k] = false;
+	if (!rc && e != hipSuccess) rc = fail(1, "hipStreamSynchronize: %s", hipGetErrorString(e));
+	return rc;
+}
+
+// ------------------------------------------------------------------------------------
 // vfgs_add_grain_line with look-ahead.
 //
 // The drop-in call hands over ONE line and must be complete on return, which costs a full
@@ -1267,6 +1373,7 @@ void vfgs_hip_shutdown(void)
 	s.tables_ring.release();
 	s.lfsr.release();
 	for (int i = 0; i < 3; i++) { if (s.stage[i]) (void)hipFree(s.stage[i]); s.stage[i] = nullptr; s.stage_cap[i] = 0; }
+	s.pipe.release();
 	for (int i = 0; i < 3; i++)
 	{
 		if (s.la.in[i]) (void)hipHostFree(s.la.in[i]);
@@ -1339,6 +1446,30 @@ int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned wi
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
 	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
+}
+
+int vfgs_hip_add_grain_frames_host(void* const* Y, void* const* U, void* const* V, unsigned nframes, unsigned width,
+                                   unsigned height, unsigned stride, unsigned cstride)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().la.valid = false;
+	return run_host_frames(Y, U, V, nframes, width, height, stride, cstride);
+}
+
+void* vfgs_hip_host_alloc(uint64_t bytes)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (ensure_init(-1)) return nullptr;
+	void* p = nullptr;
+	if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail(2, "hipHostMalloc(%llu) failed", (unsigned long long)bytes); return nullptr; }
+	return p;
+}
+
+void vfgs_hip_host_free(void* p)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (p) (void)hipHostFree(p);
 }
 
 int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV,

@@ -62,6 +62,11 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_line_lookahead.argtypes = [i]
     lib.vfgs_hip_line_lookahead.restype = None
     lib.vfgs_hip_declare_frame.argtypes = [vp, vp, vp, u, u, u, u]
+    lib.vfgs_hip_add_grain_frames_host.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u, u, u, u, u]
+    lib.vfgs_hip_host_alloc.argtypes = [C.c_uint64]
+    lib.vfgs_hip_host_alloc.restype = vp
+    lib.vfgs_hip_host_free.argtypes = [vp]
+    lib.vfgs_hip_host_free.restype = None
     _lib = lib
     return lib
 
@@ -78,6 +83,7 @@ EXPORTS = [
     "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
     "vfgs_hip_diag_stream", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
+    "vfgs_hip_add_grain_frames_host", "vfgs_hip_host_alloc", "vfgs_hip_host_free",
 ]
 
 
@@ -169,6 +175,22 @@ class VfgsHip:
 
     def declare_frame(self, Y, U, V, width, height, stride, cstride):
         self._ck(self.lib.vfgs_hip_declare_frame(Y, U, V, width, height, stride, cstride))
+
+    def add_grain_frames_host(self, Ys, Us, Vs, width, height, stride, cstride):
+        """Frames in host memory (lists of plane addresses), pipelined upload / kernel / download."""
+        n = len(Ys)
+        assert len(Us) == n and len(Vs) == n
+        arr = lambda ps: (C.c_void_p * n)(*ps)
+        self._ck(self.lib.vfgs_hip_add_grain_frames_host(arr(Ys), arr(Us), arr(Vs), n, width, height, stride, cstride))
+
+    def host_alloc(self, nbytes):
+        p = self.lib.vfgs_hip_host_alloc(nbytes)
+        if not p:
+            raise VfgsHipError(f"vfgs_hip_host_alloc({nbytes}): {self.lib.vfgs_hip_last_error_string().decode()}")
+        return p
+
+    def host_free(self, p):
+        self.lib.vfgs_hip_host_free(p)
 
     def diag_stream(self, src, dst, nbytes, mode, grid=0, stream=0):
         """Pure streaming kernels (no grain arithmetic): the copy ceiling of the chip, for bench.py."""
