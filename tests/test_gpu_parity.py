@@ -117,6 +117,24 @@ def test_8bit_subsampled_even_and_odd_block_counts(hip, name, width):
     assert hip.seed_state() == ora.seed_state()
 
 
+@pytest.mark.parametrize("name,width", [("fgs_sei_10_420", 512), ("fgs_sei_10_420", 2048), ("fgs_sei_10_420", 4096), ("fgs_sei_10_420", 8192),
+                                        ("fgs_afgs1_test1_10_444", 2048), ("fgs_sei_10_422", 4096), ("fgs_afgs1_test1_8_444", 1024),
+                                        ("fgs_afgs1_test1_8_444", 4096), ("fgs_sei_ar_test1_8_420", 8192), ("fgs_sei_10_440", 6144)])
+def test_rows_that_end_on_a_segment_or_tile_boundary(hip, name, width):
+    """Aligned kernels: a wave computes lanes shifted by half a block against the 16-byte units it moves, so a row whose
+    bytes are an exact multiple of 1 KiB (segment) or 4 KiB (tile) ends with a lane that lives alone in the NEXT segment /
+    tile, whose wave moves nothing but the tail of the unit in front of it.  Two block rows + a ragged end, device, oracle."""
+    from gpu_util import DevFrame, stream_ptr
+    ora, (depth, sx, sy) = program(hip, name)
+    f, _ = T.lcg_frames(width, 38 if sy == 1 else 40, depth, sx, sy, 1)
+    want = f[0].copy()
+    ora.add_grain_frame(want)
+    d = DevFrame(f[0])
+    hip.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), f[0].width, f[0].height, f[0].stride, f[0].cstride, stream_ptr())
+    assert d.download().equal_all(want)
+    assert hip.seed_state() == ora.seed_state()
+
+
 def test_stripes_equal_whole_frame(hip):
     """A frame fed as uneven host stripes (not multiples of 16) == line by line."""
     ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")

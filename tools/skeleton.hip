@@ -206,6 +206,39 @@ __global__ void k_flat_rmw_pers_nt(uint8_t* __restrict__ buf, size_t nbytes)
 	}
 }
 
+// persistent waves that draw 4 KiB (x ROWS) items from a device counter, in memory order: long-lived waves (tables could stay
+// in LDS) whose accesses nevertheless form one dense window.  The next ticket is drawn before the current item is moved.
+template <int LDSKB, int ROWS, int LDAUX, int STAUX>
+__global__ __launch_bounds__(256) void k_flat_rmw_ticket(uint8_t* __restrict__ buf, size_t nbytes, unsigned* counter)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[LDSKB * 1024 + 16];
+	if (LDSKB) lds[threadIdx.x] = 1;
+	const int lane = threadIdx.x & 63;
+	const unsigned nitems = (unsigned)(nbytes / ((size_t)ROWS * 4096));
+	const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)counter, 0, 4, 0x00020000);
+	auto draw = [&]() { return (unsigned)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, crs, lane == 0 ? 0u : kOOB, 0, 0); };
+	unsigned mine = (unsigned)__builtin_amdgcn_readfirstlane((int)draw());
+	while (mine < nitems)
+	{
+		const unsigned drawn = draw();          // in flight while this item moves
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + (size_t)mine * ROWS * 4096), 0, ROWS * 4096, 0x00020000);
+		u32x4 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, 0, LDAUX);
+		for (int r = 0; r < ROWS; r++)
+		{
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				__builtin_amdgcn_raw_buffer_store_b128(v[u] + (uint32_t)lds[LDSKB ? (v[u].x & 1023) : 0], rs, (u * 64 + lane) * 16, r * 4096, STAUX);
+				v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, r + 1 < ROWS ? (uint32_t)((u * 64 + lane) * 16) : kOOB, (r + 1) * 4096, LDAUX);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		mine = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
+	}
+}
+
 // the same with every access shifted by SHIFT bytes (what the grain kernel's half-block shift does to its 1 KiB accesses),
 // UPT lanes per access (the grain kernel: 62), and optionally only the 4 KiB tile shifted while its accesses stay aligned:
 // TILEMODE 1: aligned 1 KiB accesses, the tile's first 16 bytes are not stored and the 16 bytes behind it are moved by one lane
@@ -689,6 +722,8 @@ int main(int argc, char** argv)
 	uint8_t* alt;
 	for (int i = 0; i < POOL; i++) { CK(hipMalloc(&pool[i], set)); CK(hipMemset(pool[i], 0x5a + i, set)); }
 	CK(hipMalloc(&alt, set));
+	unsigned* counter;
+	CK(hipMalloc(&counter, 64));
 	uint8_t* tables;
 	CK(hipMalloc(&tables, kLdsBytes)); CK(hipMemset(tables, 3, kLdsBytes));
 	hipDeviceProp_t prop;
@@ -722,16 +757,16 @@ int main(int argc, char** argv)
 #define NP4(NAME, LDSKB, STAGE, ROWS, LA, SA, MODE) vs.push_back({NAME, [&](int s) { k_flat_rmw_np4<LDSKB, STAGE, ROWS, LA, SA, MODE><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b, tables); }, {}})
 #define NP5(NAME, LDSKB, ROWS, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_np5<LDSKB, ROWS, LA, SA><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b); }, {}})
 #define PNT(NAME, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_pers_nt<4, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b); }, {}})
+#define TKT(NAME, LDSKB, ROWS, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { CK(hipMemsetAsync(counter, 0, 4)); k_flat_rmw_ticket<LDSKB, ROWS, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b, counter); }, {}})
 	NP4("np4 36K LDS rows 1 both nt", 36, 0, 1, 2, 2, 0);
 	NP4("np4 36K LDS rows 4 rolling both nt", 36, 0, 4, 2, 2, 0);
-	NP5("np5 36K LDS rows 4 dense window both nt", 36, 4, 2, 2);
-	NP5("np5 36K LDS rows 16 dense window both nt", 36, 16, 2, 2);
-	NP5("np5 36K LDS rows 64 dense window both nt", 36, 64, 2, 2);
-	NP5("np5 36K LDS rows 4 dense window plain", 36, 4, 0, 0);
-	NP5("np5 36K LDS rows 16 dense window plain", 36, 16, 0, 0);
+	TKT("ticket 36K LDS 4 wg/cu 4 KiB items both nt", 36, 1, 4, 2, 2);
+	TKT("ticket 36K LDS 4 wg/cu 16 KiB items both nt", 36, 4, 4, 2, 2);
+	TKT("ticket 36K LDS 4 wg/cu 8 KiB items both nt", 36, 2, 4, 2, 2);
+	TKT("ticket no LDS 8 wg/cu 4 KiB items both nt", 0, 1, 8, 2, 2);
+	TKT("ticket 36K LDS 4 wg/cu 4 KiB items plain", 36, 1, 4, 0, 0);
+	TKT("ticket 36K LDS 4 wg/cu 16 KiB items plain", 36, 4, 4, 0, 0);
 	PNT("persistent grid-stride 4 wg/cu both nt", 4, 2, 2);
-	PNT("persistent grid-stride 8 wg/cu both nt", 8, 2, 2);
-	PNT("persistent grid-stride 8 wg/cu plain", 8, 0, 0);
 	NP2("np2 4KiB/wave aligned plain", 4, 0, 0, 0, 256);
 	NP2("np2 4KiB/wave aligned both nt", 4, 0, 2, 2, 256);
 	NP2("np2 4KiB/wave aligned both nt XCD-contig", 4, 1, 2, 2, 256);
