@@ -244,8 +244,8 @@ def main():
             plain = max(v for k, v in ceilings.items() if "nontemporal" not in k)
             roof["frac_of_plain_ceiling"] = round(achieved / plain, 4)
             roof["copy_ceiling_note"] = ("pure streaming kernels (vfgs_hip_diag_stream), same process, same buffers, same bytes per launch, measured right after "
-                                         "the timed region; copy_ceiling_gbs is the best of them (the nontemporal one needs line-aligned accesses by short-lived "
-                                         "waves, which the grain kernel's half-block shifted accesses are not: DESIGN.md 4), frac_of_plain_ceiling is against the best cached one")
+                                         "the timed region; copy_ceiling_gbs is the best of them (the nontemporal stream needs line-aligned accesses by waves that "
+                                         "live for one 4 KiB item; the grain kernel has the aligned accesses, its waves walk 4 rows: DESIGN.md 5), frac_of_plain_ceiling is against the best cached one")
         out = {
             "metric": "Mpixels/s (Y+UV) + achieved HBM GB/s vs roofline, 4320p 10-bit 4:2:0",
             "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
