@@ -239,6 +239,34 @@ __global__ __launch_bounds__(256) void k_flat_rmw_ticket(uint8_t* __restrict__ b
 	}
 }
 
+// np4 with SEGS x 1 KiB per wave and row instead of 4 KiB, THREADS per workgroup: smaller per-wave footprint (shorter wave lifetime,
+// smaller window) at more waves per CU.  Workgroup = (THREADS / 64) waves side by side, each walks ROWS rows of the workgroup's strip.
+template <int LDSKB, int SEGS, int ROWS, int THREADS, int LDAUX, int STAUX>
+__global__ __launch_bounds__(THREADS) void k_flat_rmw_np6(uint8_t* __restrict__ buf, size_t nbytes)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t lds[LDSKB * 1024 + 16];
+	if (LDSKB) lds[threadIdx.x] = 1;
+	const int lane = threadIdx.x & 63;
+	constexpr int WAVES = THREADS / 64;
+	constexpr uint32_t rstride = WAVES * SEGS * 1024;           // one row of the workgroup
+	const size_t base = (size_t)blockIdx.x * ROWS * rstride + (threadIdx.x >> 6) * SEGS * 1024;
+	if ((size_t)(blockIdx.x + 1) * ROWS * rstride > nbytes) return;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + base), 0, ROWS * rstride, 0x00020000);
+	u32x4 v[SEGS];
+#pragma unroll
+	for (int u = 0; u < SEGS; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, 0, LDAUX);
+	for (int r = 0; r < ROWS; r++)
+	{
+#pragma unroll
+		for (int u = 0; u < SEGS; u++)
+		{
+			__builtin_amdgcn_raw_buffer_store_b128(v[u] + (uint32_t)lds[LDSKB ? (v[u].x & 1023) : 0], rs, (u * 64 + lane) * 16, r * rstride, STAUX);
+			v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, r + 1 < ROWS ? (uint32_t)((u * 64 + lane) * 16) : kOOB, (r + 1) * rstride, LDAUX);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+}
+
 // the same with every access shifted by SHIFT bytes (what the grain kernel's half-block shift does to its 1 KiB accesses),
 // UPT lanes per access (the grain kernel: 62), and optionally only the 4 KiB tile shifted while its accesses stay aligned:
 // TILEMODE 1: aligned 1 KiB accesses, the tile's first 16 bytes are not stored and the 16 bytes behind it are moved by one lane
@@ -758,15 +786,18 @@ int main(int argc, char** argv)
 #define NP5(NAME, LDSKB, ROWS, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_np5<LDSKB, ROWS, LA, SA><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b); }, {}})
 #define PNT(NAME, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_pers_nt<4, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b); }, {}})
 #define TKT(NAME, LDSKB, ROWS, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { CK(hipMemsetAsync(counter, 0, 4)); k_flat_rmw_ticket<LDSKB, ROWS, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b, counter); }, {}})
+#define NP6(NAME, LDSKB, SEGS, ROWS, THREADS) vs.push_back({NAME, [&](int s) { k_flat_rmw_np6<LDSKB, SEGS, ROWS, THREADS, 2, 2><<<(unsigned)(set_b / ((size_t)ROWS * (THREADS / 64) * SEGS * 1024)), THREADS>>>(pool[s], set_b); }, {}})
 	NP4("np4 36K LDS rows 1 both nt", 36, 0, 1, 2, 2, 0);
 	NP4("np4 36K LDS rows 4 rolling both nt", 36, 0, 4, 2, 2, 0);
-	TKT("ticket 36K LDS 4 wg/cu 4 KiB items both nt", 36, 1, 4, 2, 2);
-	TKT("ticket 36K LDS 4 wg/cu 16 KiB items both nt", 36, 4, 4, 2, 2);
-	TKT("ticket 36K LDS 4 wg/cu 8 KiB items both nt", 36, 2, 4, 2, 2);
-	TKT("ticket no LDS 8 wg/cu 4 KiB items both nt", 0, 1, 8, 2, 2);
-	TKT("ticket 36K LDS 4 wg/cu 4 KiB items plain", 36, 1, 4, 0, 0);
-	TKT("ticket 36K LDS 4 wg/cu 16 KiB items plain", 36, 4, 4, 0, 0);
-	PNT("persistent grid-stride 4 wg/cu both nt", 4, 2, 2);
+	NP6("np6 4 segs x 4 rows, 4 waves/wg, 36K (16 waves/cu)", 36, 4, 4, 256);
+	NP6("np6 2 segs x 4 rows, 8 waves/wg, 36K (32 waves/cu)", 36, 2, 4, 512);
+	NP6("np6 2 segs x 4 rows, 8 waves/wg, 48K (24 waves/cu)", 48, 2, 4, 512);
+	NP6("np6 2 segs x 4 rows, 8 waves/wg, 72K (16 waves/cu)", 72, 2, 4, 512);
+	NP6("np6 2 segs x 4 rows, 4 waves/wg, 24K (24 waves/cu)", 24, 2, 4, 256);
+	NP6("np6 1 seg  x 4 rows, 16 waves/wg, 72K (32 waves/cu)", 72, 1, 4, 1024);
+	NP6("np6 2 segs x 2 rows, 8 waves/wg, 48K (24 waves/cu)", 48, 2, 2, 512);
+	NP6("np6 2 segs x 8 rows, 8 waves/wg, 48K (24 waves/cu)", 48, 2, 8, 512);
+	NP6("np6 4 segs x 2 rows, 4 waves/wg, 36K (16 waves/cu)", 36, 4, 2, 256);
 	NP2("np2 4KiB/wave aligned plain", 4, 0, 0, 0, 256);
 	NP2("np2 4KiB/wave aligned both nt", 4, 0, 2, 2, 256);
 	NP2("np2 4KiB/wave aligned both nt XCD-contig", 4, 1, 2, 2, 256);
