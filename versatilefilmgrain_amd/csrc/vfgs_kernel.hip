@@ -562,20 +562,40 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 		}
 	};
 
-	// ---- in flight together: the LFSR windows of my blocks, the first row's samples, the table image -----
-	u32x2 wcur[4][NR], wup[4][NR];
+	// ---- in flight together: the table image, the LFSR windows of my blocks, the first row's samples -----
+	// In THIS order: a wave's loads return in the order they were issued, so the table image and the LFSR words (L2 hits,
+	// ~1 us under load) must not queue behind the first row's samples (HBM, several us under load) -- the workgroup's
+	// barrier and the block parameters are then done by the time the samples arrive (measured with s_memrealtime marks:
+	// the barrier was passed 5.8 us after wave start with the samples first).  The instruction stream is
+	// fixed (clamped addresses and zero-record descriptors instead of branches) so that the waits can be counted.
+	constexpr int STEP = kWavesPerWG * 64 * 16;
+	constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
+	static_assert(IMG_BYTES % 16 == 0, "table image in whole 16-byte units");
+	u32x4 tmp[NIT];
+#if VFGS_ABLATE != 2
+	{
+		const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.tables + img_off, IMG_BYTES);
 #pragma unroll
-	for (int g = 0; g < 4; g++)
-#pragma unroll
-		for (int rr = 0; rr < NR; rr++)
-		{
-#if VFGS_ABLATE == 3
-			wcur[g][rr] = u32x2{(uint32_t)blk[g][rr], 7u}; wup[g][rr] = wcur[g][rr];
-#else
-			wcur[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs, ((cur_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
-			if (any_up) wup[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs, ((up_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
+		for (int it = 0; it < NIT; it++)      // threads beyond the image re-read (and re-write) its last unit
+			tmp[it] = __builtin_amdgcn_raw_buffer_load_b128(irs, min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16)), 0, 0);
+	}
 #endif
-		}
+	u32x2 wcur[4][NR], wup[4][NR];
+	{
+		const __amdgpu_buffer_rsrc_t strs_up = make_rsrc((const uint8_t*)a.stream, any_up ? a.stream_bytes : 0);
+#pragma unroll
+		for (int g = 0; g < 4; g++)
+#pragma unroll
+			for (int rr = 0; rr < NR; rr++)
+			{
+#if VFGS_ABLATE == 3
+				wcur[g][rr] = u32x2{(uint32_t)blk[g][rr], 7u}; wup[g][rr] = wcur[g][rr];
+#else
+				wcur[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs, ((cur_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
+				wup[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs_up, ((up_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
+#endif
+			}
+	}
 	// aligned mode: the last K dwords of the unit before the tile are this wave's (lane 0 of segment 0 computes them), the
 	// last K dwords of the tile's last unit are the next wave's
 	uint32_t pre[4] = {0, 0, 0, 0};
@@ -591,27 +611,10 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 		for (int g = 0; g < 4; g++) load_seg<LDA>(frs, vo[g], rowb, w[g]);
 		if (AL) load_dwords<K, LDA>(frs, preoff, rowb, pre);
 	}
-	// stage this plane type's LUTs + bank: global (L2 resident) -> LDS.  All loads are issued before the first write:
-	// a load -> wait -> write loop costs one L2 round trip per 16 bytes per thread (9 of them for the luma image), and a
-	// workgroup lives for only a few dozen microseconds
 #if VFGS_ABLATE != 2
-	{
-		constexpr int STEP = kWavesPerWG * 64 * 16;
-		constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
-		u32x4 tmp[NIT];
 #pragma unroll
-		for (int it = 0; it < NIT; it++)
-		{
-			const uint32_t i = threadIdx.x * 16 + it * STEP;
-			if (it + 1 < NIT || i < (uint32_t)IMG_BYTES) tmp[it] = *(const u32x4*)(a.tables + img_off + i);
-		}
-#pragma unroll
-		for (int it = 0; it < NIT; it++)
-		{
-			const uint32_t i = threadIdx.x * 16 + it * STEP;
-			if (it + 1 < NIT || i < (uint32_t)IMG_BYTES) *(u32x4*)(lds + i) = tmp[it];
-		}
-	}
+	for (int it = 0; it < NIT; it++)
+		*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
 #endif
 	__syncthreads();
 	if (k0 >= k1)
