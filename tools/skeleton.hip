@@ -267,6 +267,41 @@ __global__ __launch_bounds__(THREADS) void k_flat_rmw_np6(uint8_t* __restrict__ 
 	}
 }
 
+// closer to the grain kernel: workgroup of 4 waves, 36 KB table image staged first (loads before the sample loads), barrier, PRO
+// iterations of dependent VALU + LDS work once per wave (the block parameters), WORK iterations per segment (the grain), ROWS rows
+template <int ROWS, int WORK, int PRO, int LDAUX, int STAUX>
+__global__ __launch_bounds__(256) void k_flat_rmw_np8(uint8_t* __restrict__ buf, size_t nbytes, const uint8_t* tables)
+{
+	constexpr int LDSB = 36 * 1024;
+	__shared__ __attribute__((aligned(16))) uint8_t lds[LDSB];
+	const int lane = threadIdx.x & 63;
+	u32x4 tmp[9];
+#pragma unroll
+	for (int i = 0; i < 9; i++) tmp[i] = *(const u32x4*)(tables + threadIdx.x * 16 + i * 4096);
+	const size_t base = ((size_t)blockIdx.x * ROWS * 4 + (threadIdx.x >> 6)) * 4096;
+	if ((size_t)(blockIdx.x + 1) * ROWS * 16384 > nbytes) return;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + base), 0, ROWS * 16384, 0x00020000);
+	u32x4 v[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, 0, LDAUX);
+#pragma unroll
+	for (int i = 0; i < 9; i++) *(u32x4*)(lds + threadIdx.x * 16 + i * 4096) = tmp[i];
+	__syncthreads();
+	u32x4 par = {(uint32_t)lane, (uint32_t)blockIdx.x, 3u, 4u};
+	if (PRO) fake_compute(par, lds, PRO, 5u);
+	for (int r = 0; r < ROWS; r++)
+	{
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			if (WORK) fake_compute(v[u], lds, WORK, par.x & 0xff);
+			__builtin_amdgcn_raw_buffer_store_b128(v[u], rs, (u * 64 + lane) * 16, r * 16384, STAUX);
+			v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, r + 1 < ROWS ? (uint32_t)((u * 64 + lane) * 16) : kOOB, (r + 1) * 16384, LDAUX);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+}
+
 // the same with every access shifted by SHIFT bytes (what the grain kernel's half-block shift does to its 1 KiB accesses),
 // UPT lanes per access (the grain kernel: 62), and optionally only the 4 KiB tile shifted while its accesses stay aligned:
 // TILEMODE 1: aligned 1 KiB accesses, the tile's first 16 bytes are not stored and the 16 bytes behind it are moved by one lane
@@ -786,18 +821,19 @@ int main(int argc, char** argv)
 #define NP5(NAME, LDSKB, ROWS, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_np5<LDSKB, ROWS, LA, SA><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b); }, {}})
 #define PNT(NAME, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_pers_nt<4, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b); }, {}})
 #define TKT(NAME, LDSKB, ROWS, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { CK(hipMemsetAsync(counter, 0, 4)); k_flat_rmw_ticket<LDSKB, ROWS, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b, counter); }, {}})
-#define NP6(NAME, LDSKB, SEGS, ROWS, THREADS) vs.push_back({NAME, [&](int s) { k_flat_rmw_np6<LDSKB, SEGS, ROWS, THREADS, 2, 2><<<(unsigned)(set_b / ((size_t)ROWS * (THREADS / 64) * SEGS * 1024)), THREADS>>>(pool[s], set_b); }, {}})
+#define NP8(NAME, ROWS, WORK, PRO) vs.push_back({NAME, [&](int s) { k_flat_rmw_np8<ROWS, WORK, PRO, 2, 2><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b, tables); }, {}})
 	NP4("np4 36K LDS rows 1 both nt", 36, 0, 1, 2, 2, 0);
 	NP4("np4 36K LDS rows 4 rolling both nt", 36, 0, 4, 2, 2, 0);
-	NP6("np6 4 segs x 4 rows, 4 waves/wg, 36K (16 waves/cu)", 36, 4, 4, 256);
-	NP6("np6 2 segs x 4 rows, 8 waves/wg, 36K (32 waves/cu)", 36, 2, 4, 512);
-	NP6("np6 2 segs x 4 rows, 8 waves/wg, 48K (24 waves/cu)", 48, 2, 4, 512);
-	NP6("np6 2 segs x 4 rows, 8 waves/wg, 72K (16 waves/cu)", 72, 2, 4, 512);
-	NP6("np6 2 segs x 4 rows, 4 waves/wg, 24K (24 waves/cu)", 24, 2, 4, 256);
-	NP6("np6 1 seg  x 4 rows, 16 waves/wg, 72K (32 waves/cu)", 72, 1, 4, 1024);
-	NP6("np6 2 segs x 2 rows, 8 waves/wg, 48K (24 waves/cu)", 48, 2, 2, 512);
-	NP6("np6 2 segs x 8 rows, 8 waves/wg, 48K (24 waves/cu)", 48, 2, 8, 512);
-	NP6("np6 4 segs x 2 rows, 4 waves/wg, 36K (16 waves/cu)", 36, 4, 2, 256);
+	NP8("np8 staged rows 4, no work", 4, 0, 0);
+	NP8("np8 staged rows 2, no work", 2, 0, 0);
+	NP8("np8 staged rows 1, no work", 1, 0, 0);
+	NP8("np8 staged rows 4, work 12", 4, 12, 0);
+	NP8("np8 staged rows 2, work 12", 2, 12, 0);
+	NP8("np8 staged rows 4, work 12, prologue 40", 4, 12, 40);
+	NP8("np8 staged rows 2, work 12, prologue 40", 2, 12, 40);
+	NP8("np8 staged rows 2, work 12, prologue 120", 2, 12, 120);
+	NP8("np8 staged rows 4, work 24, prologue 40", 4, 24, 40);
+	NP8("np8 staged rows 2, work 24, prologue 40", 2, 24, 40);
 	NP2("np2 4KiB/wave aligned plain", 4, 0, 0, 0, 256);
 	NP2("np2 4KiB/wave aligned both nt", 4, 0, 2, 2, 256);
 	NP2("np2 4KiB/wave aligned both nt XCD-contig", 4, 1, 2, 2, 256);
