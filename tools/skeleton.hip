@@ -302,6 +302,38 @@ __global__ __launch_bounds__(256) void k_flat_rmw_np8(uint8_t* __restrict__ buf,
 	}
 }
 
+// workgroup = TW tiles x TR rows, one wave per (tile, row): every wave moves ONE 4 KiB row item, the table image is staged once per
+// workgroup of TW * TR waves; LDSKB sets how many workgroups fit a CU
+template <int TW, int TR, int LDSKB, int WORK, int PRO>
+__global__ __launch_bounds__(TW * TR * 64) void k_flat_rmw_np9(uint8_t* __restrict__ buf, size_t nbytes, const uint8_t* tables)
+{
+	constexpr int THREADS = TW * TR * 64;
+	__shared__ __attribute__((aligned(16))) uint8_t lds[LDSKB * 1024];
+	const int lane = threadIdx.x & 63;
+	constexpr int NIT = (36 * 1024 + THREADS * 16 - 1) / (THREADS * 16);
+	u32x4 tmp[NIT];
+#pragma unroll
+	for (int i = 0; i < NIT; i++) tmp[i] = *(const u32x4*)(tables + min((int)(threadIdx.x * 16 + i * THREADS * 16), 36 * 1024 - 16));
+	const size_t base = ((size_t)blockIdx.x * TW * TR + (threadIdx.x >> 6)) * 4096;
+	if ((size_t)(blockIdx.x + 1) * TW * TR * 4096 > nbytes) return;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + base), 0, 4096, 0x00020000);
+	u32x4 v[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (u * 64 + lane) * 16, 0, 2);
+#pragma unroll
+	for (int i = 0; i < NIT; i++) *(u32x4*)(lds + min((int)(threadIdx.x * 16 + i * THREADS * 16), 36 * 1024 - 16)) = tmp[i];
+	__syncthreads();
+	u32x4 par = {(uint32_t)lane, (uint32_t)blockIdx.x, 3u, 4u};
+	if (PRO) fake_compute(par, lds, PRO, 5u);
+#pragma unroll
+	for (int u = 0; u < 4; u++)
+	{
+		if (WORK) fake_compute(v[u], lds, WORK, par.x & 0xff);
+		__builtin_amdgcn_raw_buffer_store_b128(v[u], rs, (u * 64 + lane) * 16, 0, 2);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
 // the same with every access shifted by SHIFT bytes (what the grain kernel's half-block shift does to its 1 KiB accesses),
 // UPT lanes per access (the grain kernel: 62), and optionally only the 4 KiB tile shifted while its accesses stay aligned:
 // TILEMODE 1: aligned 1 KiB accesses, the tile's first 16 bytes are not stored and the 16 bytes behind it are moved by one lane
@@ -822,18 +854,18 @@ int main(int argc, char** argv)
 #define PNT(NAME, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { k_flat_rmw_pers_nt<4, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b); }, {}})
 #define TKT(NAME, LDSKB, ROWS, WGCU, LA, SA) vs.push_back({NAME, [&](int s) { CK(hipMemsetAsync(counter, 0, 4)); k_flat_rmw_ticket<LDSKB, ROWS, LA, SA><<<WGCU * cus, 256>>>(pool[s], set_b, counter); }, {}})
 #define NP8(NAME, ROWS, WORK, PRO) vs.push_back({NAME, [&](int s) { k_flat_rmw_np8<ROWS, WORK, PRO, 2, 2><<<(unsigned)(set_b / ((size_t)ROWS * 16384)), 256>>>(pool[s], set_b, tables); }, {}})
+#define NP9(NAME, TW, TR, LDSKB, WORK, PRO) vs.push_back({NAME, [&](int s) { k_flat_rmw_np9<TW, TR, LDSKB, WORK, PRO><<<(unsigned)(set_b / ((size_t)TW * TR * 4096)), TW * TR * 64>>>(pool[s], set_b, tables); }, {}})
 	NP4("np4 36K LDS rows 1 both nt", 36, 0, 1, 2, 2, 0);
-	NP4("np4 36K LDS rows 4 rolling both nt", 36, 0, 4, 2, 2, 0);
-	NP8("np8 staged rows 4, no work", 4, 0, 0);
-	NP8("np8 staged rows 2, no work", 2, 0, 0);
-	NP8("np8 staged rows 1, no work", 1, 0, 0);
-	NP8("np8 staged rows 4, work 12", 4, 12, 0);
-	NP8("np8 staged rows 2, work 12", 2, 12, 0);
 	NP8("np8 staged rows 4, work 12, prologue 40", 4, 12, 40);
 	NP8("np8 staged rows 2, work 12, prologue 40", 2, 12, 40);
-	NP8("np8 staged rows 2, work 12, prologue 120", 2, 12, 120);
-	NP8("np8 staged rows 4, work 24, prologue 40", 4, 24, 40);
-	NP8("np8 staged rows 2, work 24, prologue 40", 2, 24, 40);
+	NP9("np9 16 waves/wg (4x4) 1 row each, 36K: 2 wg/cu", 4, 4, 36, 0, 0);
+	NP9("np9 16 waves/wg (4x4) 1 row each, 100K: 1 wg/cu", 4, 4, 100, 0, 0);
+	NP9("np9 16 waves/wg, 100K, work 12 prologue 40", 4, 4, 100, 12, 40);
+	NP9("np9 16 waves/wg, 36K, work 12 prologue 40", 4, 4, 36, 12, 40);
+	NP9("np9 8 waves/wg (4x2) 1 row each, 72K: 2 wg/cu", 4, 2, 72, 0, 0);
+	NP9("np9 8 waves/wg, 72K, work 12 prologue 40", 4, 2, 72, 12, 40);
+	NP9("np9 8 waves/wg, 36K (4 wg/cu), work 12 prologue 40", 4, 2, 36, 12, 40);
+	NP9("np9 4 waves/wg (4x1), 36K (4 wg/cu), work 12 pro 40", 4, 1, 36, 12, 40);
 	NP2("np2 4KiB/wave aligned plain", 4, 0, 0, 0, 256);
 	NP2("np2 4KiB/wave aligned both nt", 4, 0, 2, 2, 256);
 	NP2("np2 4KiB/wave aligned both nt XCD-contig", 4, 1, 2, 2, 256);
