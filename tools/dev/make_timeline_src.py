@@ -13,6 +13,8 @@ def rep(old, new):
 
 rep("namespace vfgs {\n", "namespace vfgs {\n__device__ unsigned long long g_tl[16];\n__device__ __forceinline__ unsigned long long tl_now() { return __builtin_amdgcn_s_memrealtime(); }\n")
 rep("	const int pt = comp ? 1 : 0;\n", "	const int pt = comp ? 1 : 0;\n	const unsigned long long tl0 = tl_now();\n	const bool tl_on = lane == 0 && comp == 0 && (blockIdx.x % 61) == 0;     // a sample of the luma waves: the marks must not disturb\n	auto tl_mark = [&](int i) { if (tl_on) atomicAdd(&g_tl[i], tl_now() - tl0); };\n")
+rep("	constexpr int STEP = kWavesPerWG * 64 * 16;\n", "	tl_mark(7);\n	constexpr int STEP = kWavesPerWG * 64 * 16;\n")
+rep("		if (AL) load_dwords<K, LDA>(frs, preoff, rowb, pre);\n	}\n", "		if (AL) load_dwords<K, LDA>(frs, preoff, rowb, pre);\n	}\n	tl_mark(8);\n")
 rep("	__syncthreads();\n	if (k0 >= k1)\n		return;\n", "	tl_mark(1);\n	__syncthreads();\n	tl_mark(2);\n	if (k0 >= k1)\n		return;\n")
 rep("	int k = k0;\n	if (any_up)", "	tl_mark(3);\n	if (tl_on) atomicAdd(&g_tl[0], 1ull);\n	int k = k0;\n	if (any_up)")
 rep("		for (; k < k1; k++)\n			row_any(std::false_type(), k, none, 0, 0);\n	}\n}", "		for (; k < k1; k++)\n		{\n			row_any(std::false_type(), k, none, 0, 0);\n			if (k == k0) tl_mark(4);\n		}\n	}\n	tl_mark(5);\n	__builtin_amdgcn_s_waitcnt(0);\n	tl_mark(6);\n}")

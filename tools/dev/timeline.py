@@ -28,7 +28,7 @@ for i in range(50): step(i)
 e1.record(); torch.cuda.synchronize()
 h.lib.vfgs_hip_debug_timeline(out, 0)
 n = out[0]
-names = {1: "loads issued, before barrier", 2: "after barrier", 3: "block parameters done", 4: "first row done", 5: "last row done", 6: "stores drained"}
+names = {7: "geometry done (no load issued yet)", 8: "all loads issued", 1: "table image written, before barrier", 2: "after barrier", 3: "block parameters done", 4: "first row done", 5: "last row done", 6: "stores drained"}
 print("launch us", e0.elapsed_time(e1) / 50 * 1e3, "luma waves", n)
-for i in range(1, 7):
+for i in (7, 8, 1, 2, 3, 4, 5, 6):
     print(f"  {names[i]:32s} {out[i] / max(n, 1) * 0.01:8.2f} us after wave start")
