@@ -38,8 +38,13 @@ def main():
     ap.add_argument("--content", choices=["uniform", "ramp"], default="uniform",
                     help="uniform: random over the full code range (worst case for LUT / pattern divergence, SURVEY 8d); "
                          "ramp: smooth diagonal ramp + -4..+4 noise (natural-like, reported separately)")
+    ap.add_argument("--width", type=int, default=0, help="override the picture width (experiments)")
+    ap.add_argument("--height", type=int, default=0, help="override the picture height (experiments)")
     args = ap.parse_args()
     name, w, hh, depth, (sx, sy), trace, kernel = CONFIGS[args.config]
+    if args.width or args.height:
+        w, hh = args.width or w, args.height or hh
+        name += " [size %dx%d]" % (w, hh)
     import os
     if os.environ.get("VFGS_LIB"):
         hw.load(os.environ["VFGS_LIB"])      # a variant build (tools/gpu_variants.sh)

@@ -23,8 +23,9 @@
 #include "vfgs_layout.h"
 
 namespace vfgs {
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool aligned, int grid, hipStream_t stream);
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int aligned, int grid, hipStream_t stream);
 bool aligned_ok(int depth, int csubx, int nblk, bool out8);
+bool rowwalk_ok(int depth, int csubx, int nblk, bool out8);
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
 void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes);
 hipError_t launch_diag_stream(const void* src, void* dst, size_t bytes, int mode, int grid, int cu_count, hipStream_t stream);
@@ -812,7 +813,9 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	// that fills a quarter of the slots is faster with the full reuse).
 	int rows_per_wave = vfgs::kRowsPerWave;
 	const bool aligned = vfgs::aligned_ok(8 + s.bs, (int)s.csubx, (int)nblk, dg.out8);
-	for (int pass = 0; pass < 2; pass++)
+	const bool rowwalk = vfgs::rowwalk_ok(8 + s.bs, (int)s.csubx, (int)nblk, dg.out8);
+	int rw_shrink = 0;                      // row walk: halvings of the rows per wave (small launches)
+	for (int pass = 0; pass < 3; pass++)
 	{
 		long waves = 0;
 		for (int pt = 0; pt < 2; pt++)
@@ -831,6 +834,23 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 			d.rowbytes = nblk * bw * sz;
 			d.drowbytes = dg.out8 ? nblk * bw : d.rowbytes;
 			d.nrows = pt ? (int)((part_y + part_h + suby - 1) / suby) - (int)((part_y + suby - 1) / suby) : (int)part_h;
+			auto lg = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
+			if (rowwalk)
+			{
+				// a wave streams whole rows: positions = the row's units + the one behind them (the lanes compute bytes shifted
+				// by part of a unit); a workgroup = kWavesPerWG x rw_rpw rows of one block row, about 60 KB where the block row allows
+				const int units = (int)(d.rowbytes / 16);
+				d.rw_segs = (units + 1 + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
+				int rpw = 1;
+				while (vfgs::kWavesPerWG * rpw * 2 <= (int)rpb && (size_t)vfgs::kWavesPerWG * rpw * d.rowbytes < 49152) rpw *= 2;
+				for (int i = 0; i < rw_shrink && rpw > 1; i++) rpw /= 2;
+				d.rw_rpw = rpw;
+				d.rw_splits = std::max<int>(1, (int)rpb / (vfgs::kWavesPerWG * rpw));
+				d.rw_lsplits = lg(d.rw_splits);
+				d.wgs = d.nrows > 0 ? nbr_stripe * d.rw_splits : 0;
+				waves += (long)(pt ? 2 : 1) * d.wgs * vfgs::kWavesPerWG * nframes;
+				continue;
+			}
 			int shift_samples = 0, lanes = 0;
 			vfgs::lane_layout(8 + s.bs, (int)bw, (int)nblk, &shift_samples, &lanes);
 			d.segs = (lanes + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
@@ -845,20 +865,26 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 			d.ppb = std::min<int>(phases, std::max<int>(1, (int)rpb / rows_per_wave));
 			d.bpw = phases / d.ppb;
 			d.splits = std::max<int>(1, (int)rpb / (d.ppb * rows_per_wave));
-			auto lg = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
 			d.ltiles_w = lg(d.tiles_w); d.lppb = lg(d.ppb); d.lsplits = lg(d.splits);
 			const int nbgroups = (nbr_stripe + d.bpw - 1) / d.bpw;
 			d.wgs = d.nrows > 0 ? nbgroups * d.splits * d.colgroups : 0;
 			waves += (long)(pt ? 2 : 1) * d.wgs * vfgs::kWavesPerWG * nframes;
 		}
+		const long slots = (long)s.cu_count * 16;          // wave slots of the chip at this kernel's occupancy
+		if (rowwalk)
+		{
+			// a launch that leaves most wave slots empty gets more, shorter workgroups
+			if (pass < 2 && waves * 100 < VFGS_MIN_FILL_PCT * slots && (a.pd[0].rw_rpw > 1 || a.pd[1].rw_rpw > 1)) { rw_shrink++; continue; }
+			break;
+		}
 		if (pass == 0)
 		{
-			const long slots = (long)s.cu_count * 16;          // wave slots of the chip at this kernel's occupancy
 			int r = rows_per_wave;
 			while (r > 1 && waves * rows_per_wave / r * 100 < VFGS_MIN_FILL_PCT * slots) r /= 2;
 			if (r == rows_per_wave) break;
 			rows_per_wave = r;
 		}
+		else break;
 	}
 
 	// seeds: every frame of the batch runs the full state machine; frame 0's part gives the offsets
@@ -891,7 +917,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
 	if (per_frame > 0x7fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, aligned, (int)per_frame, stream));
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, rowwalk ? 2 : (aligned ? 1 : 0), (int)per_frame, stream));
 	return 0;
 }
 

@@ -788,6 +788,265 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	}
 }
 
+// ---------------------------------------------------------------------------------------
+// Row walk: the product path for pictures whose rows hold at most kTileBlocks grain blocks (8192 luma samples).
+//
+// tools/skeleton2.hip (profiles/r03_skeleton2_*.log) priced what the tiled kernels above pay besides their bytes: every
+// vector-memory INSTRUCTION queues for the CU's saturated memory pipeline, and a 4 KiB tile costs 11 of them where 8 move
+// data (the aligned kernels' narrow accesses at both tile edges), plus 8 LFSR loads per wave: 0.73 -> 0.67 of 8 TB/s.
+// Here a wave owns whole ROWS instead of a tile of several rows:
+//   * a workgroup = 4 waves = 4 x rw_rpw rows of ONE block row (wave w: rows w, w + 4, ...; the same ~60 KB and the same
+//     table image per workgroup as before); a wave streams its row segment by segment (64 aligned 16-byte units each)
+//     through a ring of four register sets -- the refill of a set is the segment four steps ahead, across row ends --
+//     so a row costs one load and one store per KiB and nothing else: no tile edges, no narrow accesses;
+//   * the block parameters of the row's <= 512 blocks (this block row's LFSR registers and, for the workgroup that holds
+//     the overlap lines, those of the block row above) are computed ONCE per workgroup, one or two blocks per thread, and
+//     kept in LDS behind the table image; a lane reads its 1-3 entries per segment (the tiled kernels hold 4 segments x
+//     1-3 runs x 2 in registers: the 8-bit 4:2:x kernels spilled on that);
+//   * lanes compute the half-block shifted bytes as in the aligned kernels (DPP rotation by one lane, the carry between
+//     consecutive segments of a row travels in SGPRs); a segment's units are stored one step later, once lane 0 of the next
+//     segment has delivered the last dwords of its lane 63;
+//   * row bases and segment offsets live in the buffer descriptor (base, num_records = bytes of the row left), so the
+//     hardware range check covers every access of every lane: lanes behind the row's end load 0 and store nothing.
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE>
+__device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, const int r,
+                                             const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
+{
+	constexpr int NS = DEPTH == 8 ? 16 : 8;
+	constexpr int SZ = DEPTH > 8 ? 2 : 1;
+	using M = LaneMap<NS, BW>;
+	constexpr int NR = M::NR;
+	constexpr int RPB = 16 / SUBY;                       // rows of this plane per block row
+	constexpr int NEF = M::PAIR ? 1 : M::NE;
+	constexpr int K = M::SHIFT * SZ / 4;                 // dwords of a lane that lie in the memory unit before the lane's own
+	constexpr int LDA = VFGS_LDAUX_ALIGNED, STA = VFGS_STAUX_ALIGNED;
+	constexpr int LPB = M::PAIR ? 1 : M::BPL;            // blocks per lane step (PAIR: half a block, see idx0 below)
+	constexpr int BPS = M::PAIR ? 32 : 64 * M::BPL;      // grain blocks a segment advances by
+	constexpr uint32_t PT_CUR = IMG_BYTES, PT_UP = IMG_BYTES + kParamTableBytes;
+	static_assert(IMG_BYTES % 16 == 0, "table image in whole 16-byte units");
+	const int pt = comp ? 1 : 0;
+	auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+
+	// ---- the workgroup's place: block row of the stripe, part of it; the wave's rows -------------------------------
+	const int split = r & (pd.rw_splits - 1);
+	const int kbr = uni(r >> pd.rw_lsplits);             // block row inside the stripe
+	const int Rabs = (a.y0 >> 4) + kbr;                  // absolute block row
+	const int row_first = (a.y0 + SUBY - 1) / SUBY;      // first row of the stripe in this plane; the plane pointers address row y0 / SUBY
+	const int prow0 = a.y0 / SUBY;
+	const int alo = max(row_first, Rabs * RPB), ahi = min(row_first + pd.nrows, (Rabs + 1) * RPB);
+	const int rpw = pd.rw_rpw;
+#if VFGS_RW_CONSEC
+	const int RSTR = 1;                                  // a wave's rows are consecutive (a contiguous stream where the rows are)
+	const int base = uni(Rabs * RPB + split * (kWavesPerWG * rpw) + wave * rpw);     // my rows: base + RSTR * k, k in [k0, k1)
+	int k0 = max(0, alo - base), k1 = min(rpw, max(0, ahi - base));
+#else
+	constexpr int RSTR = kWavesPerWG;                    // the waves of a workgroup walk down its rows side by side
+	const int base = uni(Rabs * RPB + split * (kWavesPerWG * rpw) + wave);
+	int k0 = (max(0, alo - base) + kWavesPerWG - 1) / kWavesPerWG, k1 = min(rpw, (max(0, ahi - base) + kWavesPerWG - 1) / kWavesPerWG);
+#endif
+	if (kbr >= a.nbrows || k1 < k0) k1 = k0;
+	k0 = uni(k0); k1 = uni(k1);
+	const bool wg_up = (Rabs > 0) && (split == 0);       // this workgroup holds the overlap lines of its block row (vfgs_hw.c:175,180)
+
+	const int last = a.nblk - 1;
+	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(kbr * a.nblk);
+	const uint32_t up_bit = (kbr > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
+
+	// ---- in flight together: the table image, the LFSR words of the row's blocks, my first four segments -----------
+	// (in this order: a wave's loads return in issue order; fixed instruction stream)
+	constexpr int STEP = kWavesPerWG * 64 * 16;
+	constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
+	u32x4 tmp[NIT];
+#if defined(VFGS_RW_ABLATE) && VFGS_RW_ABLATE >= 2
+#pragma unroll
+	for (int it = 0; it < NIT; it++) tmp[it] = u32x4{1, 2, 3, 4};
+#else
+	{
+		const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.tables + img_off, IMG_BYTES);
+#pragma unroll
+		for (int it = 0; it < NIT; it++)      // threads beyond the image re-read (and re-write) its last unit
+			tmp[it] = __builtin_amdgcn_raw_buffer_load_b128(irs, min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16)), 0, 0);
+	}
+#endif
+	// parameter table entry e = block e - 1 (clamped into the row): thread t fills entries t, t + 256, ...
+	constexpr int NPE = (kParamEntries + kWavesPerWG * 64 - 1) / (kWavesPerWG * 64);
+	u32x2 wc[NPE], wu[NPE];
+	{
+		const __amdgpu_buffer_rsrc_t strs = make_rsrc((const uint8_t*)a.stream, a.stream_bytes);
+		const __amdgpu_buffer_rsrc_t strs_up = make_rsrc((const uint8_t*)a.stream, wg_up ? a.stream_bytes : 0);
+#pragma unroll
+		for (int i = 0; i < NPE; i++)
+		{
+			const int e = (int)threadIdx.x + i * kWavesPerWG * 64;
+			const uint32_t blk = (uint32_t)min(max(e - 1, 0), last);
+#if defined(VFGS_RW_ABLATE) && VFGS_RW_ABLATE >= 3
+			const bool need = false;
+#else
+			const bool need = e < a.nblk + 4 && e < kParamEntries;
+#endif
+			wc[i] = __builtin_amdgcn_raw_buffer_load_b64(strs, need ? ((cur_bit + blk) >> 5) * 4 : kOOB, 0, 0);
+			wu[i] = __builtin_amdgcn_raw_buffer_load_b64(strs_up, need ? ((up_bit + blk) >> 5) * 4 : kOOB, 0, 0);
+		}
+	}
+	// A row = rw_segs wave accesses ("positions": its units and the one behind them), walked in groups of four: the four
+	// register sets.  One buffer descriptor serves a whole group: base = the first byte of the group, num_records = the
+	// bytes the row has left from there (at most the group's 4 KiB), the segment's 1 KiB step sits in the instruction's
+	// immediate offset: the hardware range check switches off exactly the lanes behind the row's end -- and every lane of a
+	// group that does not exist -- and no access of any lane can leave the row.  (Measured on gfx950: a scalar offset
+	// operand IS part of what is checked against num_records, so the row offset has to go into the base.)
+	const int tsegs = pd.rw_segs;
+	const int ngroups = (tsegs + 3) >> 2;
+	const uint8_t* sbase = a.src[comp] + (uint64_t)f * pd.fpitch;
+	uint8_t* dbase = a.dst[comp] + (uint64_t)f * pd.dfpitch;
+	const uint32_t lane16 = (uint32_t)lane * 16;
+	constexpr uint32_t GB = 4 * kMaxUnits * 16;          // bytes of a group
+	auto row_off = [&](int k) { return (uint32_t)((base + RSTR * k - prow0) * (int)pd.pitch); };
+	auto left = [&](int g) { const uint32_t o = (uint32_t)g * GB; return o < pd.rowbytes ? min(pd.rowbytes - o, GB) : 0u; };
+	uint32_t w[4][4];
+	{
+		const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(sbase + (k0 < k1 ? row_off(k0) : 0u), k0 < k1 ? left(0) : 0u);
+#pragma unroll
+		for (int u = 0; u < 4; u++) load_seg<LDA>(rs0, lane16 + u * (kMaxUnits * 16), 0, w[u]);
+	}
+#if !(defined(VFGS_RW_ABLATE) && VFGS_RW_ABLATE >= 2)
+#pragma unroll
+	for (int it = 0; it < NIT; it++)
+		*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
+#endif
+
+	// ---- block parameters of the row (once per workgroup) ----------------------------------------------------------
+	const int fsx = comp == 0 ? 0 : (comp == 1 ? 10 : 20);
+	const int fsy = comp == 0 ? 14 : (comp == 1 ? 24 : 4);
+	const int fsb = comp == 0 ? 31 : (comp == 1 ? 2 : 15);
+#pragma unroll
+	for (int i = 0; i < NPE; i++)
+	{
+		const int e = (int)threadIdx.x + i * kWavesPerWG * 64;
+		const uint32_t blk = (uint32_t)min(max(e - 1, 0), last);
+		bool neg;
+		const uint32_t vc = __builtin_amdgcn_alignbit(wc[i].y, wc[i].x, (cur_bit + blk) & 31);
+		const uint32_t pc = block_param<SUBX, SUBY, RS, ONE>(vc, bank_off, fsx, fsy, fsb, &neg) | (neg ? 0x80000000u : 0u);
+		const uint32_t vu = __builtin_amdgcn_alignbit(wu[i].y, wu[i].x, (up_bit + blk) & 31);
+		const uint32_t pu = block_param<SUBX, SUBY, RS, ONE>(vu, bank_off, fsx, fsy, fsb, &neg) | (neg ? 0x80000000u : 0u);
+		if (e < kParamEntries)
+		{
+			*(uint32_t*)(lds + PT_CUR + e * 4) = pc;
+			*(uint32_t*)(lds + PT_UP + e * 4) = pu;
+		}
+	}
+	__syncthreads();
+	if (k0 >= k1)
+		return;
+
+	// ---- per lane constants ------------------------------------------------------------------------------------------
+	const uint32_t lutb = lut_off * 0x10001u;
+	const uint32_t lo2 = a.lo2[pt], hi2 = a.hi2[pt];
+	const bool first = M::PAIR && (lane & 1);                              // PAIR: odd lane positions hold the first half of a block
+	const uint32_t pairoff = M::PAIR ? (first ? 0u : 8u * (ONE ? 1 : kSlots)) : 0u;
+	const uint32_t idx0 = (M::PAIR ? (uint32_t)(lane + 1) >> 1 : (uint32_t)lane * LPB) * 4;   // byte offset of my first entry in segment 0
+	const int cl = M::PAIR ? lane - 1 - (lane & 1) : lane * LPB - 1;       // PAIR: left unit of my lane pair; else: block of run 0 (both for segment 0)
+	constexpr int SSTEP = M::PAIR ? 64 : BPS;                              // what `cl` advances by per segment
+	// DPP moves by one lane; lanes without a source lane (lane 0 / lane 63) keep `old`; the rotations wrap around
+	auto lane_up = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false); };    // wave_shr:1: lane l <- lane l - 1
+	auto lane_down = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130, 0xf, 0xf, false); };  // wave_shl:1: lane l <- lane l + 1
+	auto rot_up = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13c, 0xf, 0xf, false); };      // wave_ror:1: lane 0 <- lane 63
+	auto rot_down = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134, 0xf, 0xf, false); };    // wave_rol:1: lane 63 <- lane 0
+
+	// ---- the walk ----------------------------------------------------------------------------------------------------
+	uint32_t carry[4] = {0, 0, 0, 0};      // in lane 0: the last K dwords of lane 63 of the previous segment of the row
+	uint32_t outp[4] = {0, 0, 0, 0};       // the previous segment's units: dwords K.. of its lanes (the first 4 - K dwords of a unit)
+	uint32_t tp[4] = {0, 0, 0, 0};         // ... and the first K dwords its lanes computed: they belong one lane down
+	__amdgpu_buffer_rsrc_t pdst = make_rsrc(dbase, 0);     // where the previous GROUP's last segment goes
+	// one row; `overlap` is a type so that the walk of the (rare) overlap lines is code of its own: the hot loop carries
+	// neither their arithmetic nor a branch around it
+	auto walk_row = [&](auto overlap, const int k) {
+		constexpr bool OV = decltype(overlap)::value;
+		const int j = base + RSTR * k - Rabs * RPB;    // row inside the block row
+		const int jrow = j * SUBY;
+		const uint32_t rowoff = (uint32_t)j * RS, uprowoff = (uint32_t)(RPB + j) * RS;
+		const int wc_ = jrow == 0 ? (SUBY > 1 ? 20 : 12) : 24, wu_ = jrow == 0 ? (SUBY > 1 ? 20 : 24) : 12;
+		const uint32_t ro = row_off(k);
+		for (int g = 0; g < ngroups; g++)
+		{
+			// the group after this one (this row's next, or the next row's first): what the four refills fetch
+			const bool lastg = g + 1 == ngroups;
+			const int ng = lastg ? 0 : g + 1;
+			const bool nvalid = !lastg || k + 1 < k1;
+			const uint32_t nso = nvalid ? (lastg ? row_off(k + 1) : ro) + (uint32_t)ng * GB : 0u;
+			const __amdgpu_buffer_rsrc_t nsrc = make_rsrc(sbase + nso, nvalid ? left(ng) : 0u);
+			const __amdgpu_buffer_rsrc_t cdst = make_rsrc(dbase + (ro + (uint32_t)g * GB), left(g));
+			const uint8_t* pe = lds + idx0 + (uint32_t)(g * 4 * BPS * 4);
+			const int clg = cl + g * 4 * SSTEP;
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				const bool firsts = u == 0 && g == 0;                    // first segment of the row
+				// assemble my 16 bytes: the last K dwords of the unit of the lane before me, the first 4 - K of mine
+				uint32_t t[4];
+#pragma unroll
+				for (int d = 0; d < K; d++) t[d] = lane_up(firsts ? 0u : carry[d], w[u][4 - K + d]);   // (in front of a row there is nothing)
+#pragma unroll
+				for (int d = 0; d < K; d++) carry[d] = rot_up(w[u][4 - K + d]);
+				// (real copies: were t[] merely another name for these registers, the refill below would have to land somewhere
+				// else and be copied back at the end of the loop -- behind a wait for all four refills)
+#pragma unroll
+				for (int d = K; d < 4; d++) asm volatile("v_mov_b32 %0, %1" : "=v"(t[d]) : "v"(w[u][d - K]));
+				// the registers are free: refill them with the segment four steps ahead
+				load_seg<LDA>(nsrc, lane16 + u * (kMaxUnits * 16), 0, w[u]);
+#if defined(VFGS_RW_ABLATE) && VFGS_RW_ABLATE >= 1       // timing experiments only (tools/dev/build_variant.sh): copy, WRONG output
+				if (false)
+#else
+				if (4 * g + u < tsegs)
+#endif
+				{
+					bool edge_on[NEF];
+					if (M::PAIR)
+					{
+						const int jl = clg + u * SSTEP;                    // left unit of this lane pair
+						edge_on[0] = jl >= 0 && jl + 1 < 2 * a.nblk;
+					}
+					else
+					{
+#pragma unroll
+						for (int ed = 0; ed < M::NE; ed++) edge_on[ed] = (clg + u * SSTEP + ed >= 0) && (clg + u * SSTEP + ed < last);
+					}
+					RunParam<NR> rp, up;
+#pragma unroll
+					for (int rr = 0; rr < NR; rr++) rp.pa[rr] = *(const uint32_t*)(pe + PT_CUR + (u * BPS + rr) * 4) + pairoff;
+#pragma unroll
+					for (int rr = 0; rr < NR; rr++) up.pa[rr] = OV ? *(const uint32_t*)(pe + PT_UP + (u * BPS + rr) * 4) + pairoff : 0u;
+					grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2>(lds, t, rp, up, lutb, rowoff, uprowoff, OV ? wc_ : 0, OV ? wu_ : 0, edge_on, first, lo2, hi2);
+				}
+				// the previous segment's units are complete once the K dwords its lanes computed have moved one lane down; its
+				// lane 63 takes them from my lane 0 (the previous segment of a row's first one is the last of another row:
+				// its lane 63 lies behind that row's end and is never stored)
+#pragma unroll
+				for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(rot_down(t[d]), tp[d]);
+				if (u == 0) store_b128<STA>(pdst, lane16 + 3 * (kMaxUnits * 16), 0, outp);
+				else store_b128<STA>(cdst, lane16 + (u - 1) * (kMaxUnits * 16), 0, outp);
+#pragma unroll
+				for (int d = K; d < 4; d++) outp[d - K] = t[d];
+#pragma unroll
+				for (int d = 0; d < K; d++) tp[d] = t[d];
+#if VFGS_SCHED_FENCE
+				__builtin_amdgcn_sched_barrier(0);
+#endif
+			}
+			pdst = cdst;
+		}
+	};
+	for (int k = k0; k < k1; k++)
+	{
+		const int jrow = (base + RSTR * k - Rabs * RPB) * SUBY;
+		if (Rabs > 0 && jrow <= 1) walk_row(std::true_type(), k);      // blends in the block above (vfgs_hw.c:173-188, 223-229)
+		else walk_row(std::false_type(), k);
+	}
+	// the last segment of my last row
+#pragma unroll
+	for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(0u, tp[d]);
+	store_b128<STA>(pdst, lane16 + 3 * (kMaxUnits * 16), 0, outp);
+}
+
 // 8-bit planes with 8-sample blocks hold three block runs and two edges per lane (LaneMap): those kernels get the
 // registers of one workgroup less per CU instead of spilling in the row loop
 template <int DEPTH, int CSUBX>
@@ -817,6 +1076,28 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * wg_per_cu<DEPTH, C
 	}
 }
 
+// row-walk kernel (run_plane_rw): in place or out of place, same sample size; workgroups numbered frame -> plane -> block row -> part
+template <int DEPTH, int CSUBX, int CSUBY, bool ONEY, bool ONEC>
+__global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4) void grain_rw_kernel(const KernelArgs a)
+{
+	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
+	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes + kParamBytes];
+
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int f = blockIdx.y;
+	int r = blockIdx.x;
+	if (r < a.pd[0].wgs)
+		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+	else
+	{
+		r -= a.pd[0].wgs;
+		const int comp = 1 + (r >= a.pd[1].wgs);
+		if (comp == 2) r -= a.pd[1].wgs;
+		run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+	}
+}
+
 // ---------------------------------------------------------------------------------------
 // host-side launcher (called from vfgs_host.cpp)
 
@@ -833,17 +1114,25 @@ template <int DEPTH, int CSUBX>
 constexpr bool has_shifted() { return !VFGS_ALIGNED || (DEPTH == 8 && CSUBX == 2); }
 
 template <int DEPTH, int CSUBX, int CSUBY, bool ONEY, bool ONEC>
-static hipError_t launch_al(const KernelArgs& a, bool aligned, int grid, hipStream_t stream)
+static hipError_t launch_al(const KernelArgs& a, int mode, int grid, hipStream_t stream)
 {
+	const bool aligned = mode != 0;
 	if constexpr (VFGS_ALIGNED != 0)
+	{
+		if (mode == 2)
+		{
+			hipLaunchKernelGGL((grain_rw_kernel<DEPTH, CSUBX, CSUBY, ONEY, ONEC>), dim3(grid, a.nframes), dim3(kWavesPerWG * 64), 0, stream, a);
+			return hipGetLastError();
+		}
 		if (aligned) return launch_t<DEPTH, CSUBX, CSUBY, false, ONEY, ONEC, true>(a, grid, stream);
+	}
 	if constexpr (has_shifted<DEPTH, CSUBX>())
 		return launch_t<DEPTH, CSUBX, CSUBY, false, ONEY, ONEC, false>(a, grid, stream);
 	return hipErrorInvalidValue;
 }
 
 template <int DEPTH, int CSUBX, int CSUBY>
-static hipError_t launch_one(const KernelArgs& a, bool out8, bool oney, bool onec, bool aligned, int grid, hipStream_t stream)
+static hipError_t launch_one(const KernelArgs& a, bool out8, bool oney, bool onec, int aligned, int grid, hipStream_t stream)
 {
 	if (DEPTH == 10 && out8) return launch_t<10, CSUBX, CSUBY, true, false, false, false>(a, grid, stream);    // fused 8-bit output: general form, shifted accesses
 	if (oney && onec) return launch_al<DEPTH, CSUBX, CSUBY, true, true>(a, aligned, grid, stream);
@@ -853,8 +1142,9 @@ static hipError_t launch_one(const KernelArgs& a, bool out8, bool oney, bool one
 }
 
 // oney / onec: the image holds the one-pattern form for luma / chroma (vfgs_layout.h); never with out8.
-// aligned: the plane descriptors were laid out for the aligned kernels (aligned_ok()).
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool aligned, int grid, hipStream_t stream)
+// aligned: 0 = the plane descriptors were laid out for the kernels with shifted accesses, 1 = for the aligned tiled kernels
+// (aligned_ok()), 2 = for the row walk (rowwalk_ok()).
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int aligned, int grid, hipStream_t stream)
 {
 	if (out8 && (depth != 10 || oney || onec || aligned)) return hipErrorInvalidValue;
 #define VFGS_CASE(D, X, Y) if (depth == D && csubx == X && csuby == Y) return launch_one<D, X, Y>(a, out8, oney, onec, aligned, grid, stream)
@@ -869,6 +1159,15 @@ bool aligned_ok(int depth, int csubx, int nblk, bool out8)
 {
 	if (!VFGS_ALIGNED || out8) return false;
 	return !(depth == 8 && csubx == 2 && (nblk & 1));
+}
+
+// ... the row walk?  (additionally: a row's blocks fit the workgroup's parameter table)
+bool rowwalk_ok(int depth, int csubx, int nblk, bool out8)
+{
+#ifdef VFGS_NO_ROWWALK
+	return false;
+#endif
+	return aligned_ok(depth, csubx, nblk, out8) && nblk <= kTileBlocks;
 }
 
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec) { return image_layout(csubx, csuby, oney, onec); }

@@ -58,8 +58,20 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #define VFGS_STAUX_ALIGNED 2
 #endif
 
+#ifndef VFGS_RW_CONSEC
+#define VFGS_RW_CONSEC 0      // row walk: 1 = a wave's rows are consecutive, 0 = the waves of a workgroup take every kWavesPerWG-th row
+#endif
+
 constexpr int kWavesPerWG = VFGS_WAVES;
 constexpr int kRowsPerWave = VFGS_ROWS_PER_WAVE;
+
+// Row-walk kernels (vfgs_kernel.hip "Row walk"): a wave streams whole rows, the workgroup's block parameters live in LDS
+// behind the table image: two tables (this block row's registers, the block row above's) of one dword per grain block of the
+// row + one block in front.  A row of at most kTileBlocks blocks is one tile; wider pictures keep the tiled kernels.
+constexpr int kTileBlocks = 512;
+constexpr int kParamEntries = kTileBlocks + 4;   // entry e = block e - 1; the lanes behind a row's end read up to block nblk + 2 (clamped values)
+constexpr int kParamTableBytes = (kParamEntries * 4 + 15) & ~15;
+constexpr int kParamBytes = 2 * kParamTableBytes;
 
 // Device image of everything the kernel looks up: one sub-image per plane type (luma; chroma) -- or per chroma
 // component -- and a workgroup (which works on ONE plane) copies the sub-image of its plane to LDS offset 0.
@@ -139,6 +151,9 @@ struct PlaneDesc {
 	int ltiles_w, lppb, lsplits;     // their logarithms
 	int colgroups;                // workgroups along a row = ceil(tiles / tiles_w)
 	int wgs;                      // workgroups per frame for ONE plane of this type
+	// row walk: a workgroup = kWavesPerWG waves x rw_rpw rows each (wave w: rows w, w + kWavesPerWG, ... of the workgroup's
+	// part of ONE block row), rw_splits workgroups per block row; a row = rw_segs wave accesses of 64 units
+	int rw_segs, rw_rpw, rw_splits, rw_lsplits;
 };
 
 // One launch = nframes x (luma workgroups + 2 x chroma workgroups); workgroups are numbered in memory
