@@ -20,6 +20,14 @@ frames' worth at every N ("weak").  At N=1 a step is `batch` whole frames in one
 `cpu_baseline` = the REAL reference hardware layer (oracle/_ref/libvfgs_ref.so, kind
             "reference") if that prebuilt file travelled to this box, else this repo's oracle
             ("port"), one host core, on a bounded number of frames of the same workload.
+`parity_checked` = after the timed region one more launch of exactly the timed shape (same entry point, same frames per
+            launch, in place) runs on freshly generated frames from a reset seed state, and every frame of it is compared
+            with the oracle on the host (each rank its own stripes); true only if every byte and the seed registers agree.
+
+`--gpus N` without a launcher around it (WORLD_SIZE unset): this process starts `python -m torch.distributed.run` with N
+ranks as a CHILD process -- before anything touches the GPU -- and relays its output and exit code.
+`--scaling weak` (default): a step = N x batch frames, per-GPU work constant in N.  `--scaling strong`: a step = batch
+frames whatever N is, every frame's block rows split over the N ranks (the latency view: one frame's stripes on N GPUs).
 """
 import argparse
 import ctypes as C
@@ -108,7 +116,27 @@ def main():
     ap.add_argument("--no-ceiling", action="store_true", help="skip the same-process copy ceiling")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="developer option: run the N-rank code path with all ranks on cuda:0")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: a step is gpus*batch frames; strong: a step is batch frames split over the ranks")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-timing parity launch")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  A child process (never exec: this box forbids replacing a process image once
+        # a GPU has been touched, and nothing here has touched one yet), its stdout relayed line by line.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+        for line in child.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        sys.exit(child.wait())
 
     import torch
     import torch.distributed as dist
@@ -134,7 +162,8 @@ def main():
     nbr = (H + 15) // 16
     row0, nrows = split_rows(nbr, world)[rank]
     part_y, part_h = row0 * 16, min(nrows * 16, H - row0 * 16)
-    frames_per_launch = world * args.batch       # rank r: its stripe of each of these frames
+    # rank r: its stripe of each of these frames (weak: per-GPU work constant in N; strong: the job's work constant in N)
+    frames_per_launch = world * args.batch if args.scaling == "weak" else args.batch
     stride, cstride = W, W // SUBX
     ypitch = part_h * stride * 2                 # bytes between consecutive frames' stripes
     cpitch = (part_h // SUBY) * cstride * 2
@@ -202,8 +231,45 @@ def main():
         ceilings["inplace_rmw_nontemporal_one_wg_per_16KiB"] = timed(lambda k: h.diag_stream(0, base[k % pool], set_bytes, 3, 0, stream))
         ceilings["out_of_place_uint4_copy"] = timed(lambda k: h.diag_stream(base[k % pool], base[(k + 1) % pool], set_bytes, 0, 8 * cus, stream))
 
+    # ---- parity of what was timed: one more launch of the same shape, from pristine frames and a reset seed state, every
+    # frame against the oracle (this rank's stripes; rows outside them are not this rank's business and stay zero) ----
+    parity = None
+    if not args.no_parity:
+        import numpy as np
+        rec = T.load_trace(TRACE)
+        h.lib.vfgs_hip_reset_state()
+        T.replay(h, rec)
+        ora = T.OracleHW()
+        T.replay(ora, rec)
+        gp = torch.Generator(device="cuda").manual_seed(977 + rank)
+        sets[0].copy_(torch.randint(0, 1024, (ny + 2 * nc,), dtype=torch.int16, device="cuda", generator=gp))
+        src = sets[0].cpu().numpy().view(np.uint16)
+        step(0)
+        torch.cuda.synchronize()
+        got = sets[0].cpu().numpy().view(np.uint16)
+        crow0, crows = part_y // SUBY, part_h // SUBY
+        bad = 0
+        for f in range(frames_per_launch):
+            fr = T.Frame(W, H, DEPTH, SUBX, SUBY, stride=stride, cstride=cstride)
+            yo, uo, vo = f * part_h * stride, ny + f * crows * cstride, ny + nc + f * crows * cstride
+            fr.Y[part_y:part_y + part_h] = src[yo:yo + part_h * stride].reshape(part_h, stride)
+            fr.U[crow0:crow0 + crows] = src[uo:uo + crows * cstride].reshape(crows, cstride)
+            fr.V[crow0:crow0 + crows] = src[vo:vo + crows * cstride].reshape(crows, cstride)
+            ora.add_grain_frame(fr)
+            ok = (np.array_equal(fr.Y[part_y:part_y + part_h].ravel(), got[yo:yo + part_h * stride])
+                  and np.array_equal(fr.U[crow0:crow0 + crows].ravel(), got[uo:uo + crows * cstride])
+                  and np.array_equal(fr.V[crow0:crow0 + crows].ravel(), got[vo:vo + crows * cstride]))
+            bad += not ok
+        parity = bad == 0 and h.seed_state() == ora.seed_state()
+        if not parity:
+            print(f"bench.py: rank {rank}: PARITY FAILURE: {bad} of {frames_per_launch} frames differ from the oracle", file=sys.stderr)
+
     n_seen, per_rank_us = 1, [round(launch_ms * 1e3, 2)]
     if world > 1:
+        if parity is not None:
+            pt_ = torch.tensor([1 if parity else 0], dtype=torch.int64)
+            dist.all_reduce(pt_, op=dist.ReduceOp.MIN)
+            parity = bool(pt_.item())
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -234,7 +300,7 @@ def main():
                                   "kernel_sha16_profiled": rec.get("kernel_sha16")}
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "grain_kernel<10,2,2,false,false,true,true> (depth 10, 4:2:0, in place; luma general form, chroma one-pattern form, aligned nontemporal accesses)", "launch_us": round(launch_ms * 1e3, 2),
+                "kernel": "grain_rw_kernel<10,2,2,false,true> (depth 10, 4:2:0, in place; luma general form, chroma one-pattern form; row walk, aligned nontemporal accesses)", "launch_us": round(launch_ms * 1e3, 2),
                 "algorithmic_bytes_per_launch": bytes_per_launch}
         if ceilings:
             best = max(ceilings.values())
@@ -245,11 +311,11 @@ def main():
             roof["frac_of_plain_ceiling"] = round(achieved / plain, 4)
             roof["copy_ceiling_note"] = ("pure streaming kernels (vfgs_hip_diag_stream), same process, same buffers, same bytes per launch, measured right after "
                                          "the timed region; copy_ceiling_gbs is the best of them (the nontemporal stream needs line-aligned accesses by waves that "
-                                         "live for one 4 KiB item; the grain kernel has the aligned accesses, its waves walk 4 rows: DESIGN.md 5), frac_of_plain_ceiling is against the best cached one")
+                                         "live for one 4 KiB item; the grain kernel has the aligned accesses, its waves stream whole rows: DESIGN.md 5), frac_of_plain_ceiling is against the best cached one")
         out = {
             "metric": "Mpixels/s (Y+UV) + achieved HBM GB/s vs roofline, 4320p 10-bit 4:2:0",
             "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": "7680x4320 10-bit 4:2:0, cfg fgs_sei (8 luma patterns), seed 12345, uniform random samples",
                        "frames_per_step": frames_per_launch, "stripe_split": f"{world} x block-row stripes",
@@ -258,6 +324,7 @@ def main():
                        "sync_backend": "gloo (barrier + max only; no collective on the data path)" if world > 1 else "none",
                        "n_ranks_seen": n_seen, "launch_us_per_rank": per_rank_us},
             "roofline": roof,
+            "parity_checked": parity,
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()

@@ -700,6 +700,9 @@ int main(int argc, char** argv)
 		NP8E("np8e rows 4, work 15, pro 40, +0 prologue loads, +0 narrow", 4, 15, 40, 0, 0);
 		NP8E("np8e rows 4, work 15, pro 40, +8 prologue, +3 narrow (= shipped counts)", 4, 15, 40, 8, 1);
 		NP10("np10 row walk 16 segs x 1 row, work 15, pro 40, +8 prologue, 2 param reads", 16, 1, 15, 40, 8, 2);
+		NP10("np10 row walk 12 segs x 1 row (12 KiB rows), no work", 12, 1, 0, 0, 0, 0);
+		NP10("np10 row walk 20 segs x 1 row (20 KiB rows), no work", 20, 1, 0, 0, 0, 0);
+		NP10("np10 row walk 12 segs x 1 row, work 15, pro 40, +8, 2 param reads", 12, 1, 15, 40, 8, 2);
 		NP10("np10 row walk 16 segs x 1 row, work 15, pro 40, +0 prologue, 2 param reads", 16, 1, 15, 40, 0, 2);
 		NP10("np10 row walk 16 segs x 1 row, work 15, pro 40, +8, no param reads", 16, 1, 15, 40, 8, 0);
 		NP10("np10 row walk 16 segs x 1 row, no work", 16, 1, 0, 0, 0, 0);
