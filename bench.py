@@ -225,11 +225,19 @@ def main():
             return 2.0 * set_bytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9     # every byte read once + written once
         base = [b.data_ptr() for b in sets]
         cus = h.device_info()["cu_count"]
-        ceilings["inplace_rmw_4KiB_per_wave_8wg_per_cu"] = timed(lambda k: h.diag_stream(0, base[k % pool], set_bytes, 1, 8 * cus, stream))
-        ceilings["inplace_rmw_4KiB_per_wave_12wg_per_cu"] = timed(lambda k: h.diag_stream(0, base[k % pool], set_bytes, 1, 12 * cus, stream))
-        ceilings["inplace_rmw_4KiB_per_wave_one_wg_per_16KiB"] = timed(lambda k: h.diag_stream(0, base[k % pool], set_bytes, 2, 0, stream))
-        ceilings["inplace_rmw_nontemporal_one_wg_per_16KiB"] = timed(lambda k: h.diag_stream(0, base[k % pool], set_bytes, 3, 0, stream))
-        ceilings["out_of_place_uint4_copy"] = timed(lambda k: h.diag_stream(base[k % pool], base[(k + 1) % pool], set_bytes, 0, 8 * cus, stream))
+        # bench-only streaming kernels, a library of their own (tools/bench_diag.hip; not part of the product or its ABI)
+        from versatilefilmgrain_amd import build as vbuild
+        dlib = C.CDLL(str(vbuild.build_diag()))
+        dlib.vfgs_bench_diag_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+
+        def diag(src, dst, mode, grid):
+            rc = dlib.vfgs_bench_diag_stream(src, dst, set_bytes, mode, grid, cus, stream)
+            assert rc == 0, f"vfgs_bench_diag_stream: hipError {rc}"
+        ceilings["inplace_rmw_4KiB_per_wave_8wg_per_cu"] = timed(lambda k: diag(0, base[k % pool], 1, 8 * cus))
+        ceilings["inplace_rmw_4KiB_per_wave_12wg_per_cu"] = timed(lambda k: diag(0, base[k % pool], 1, 12 * cus))
+        ceilings["inplace_rmw_4KiB_per_wave_one_wg_per_16KiB"] = timed(lambda k: diag(0, base[k % pool], 2, 0))
+        ceilings["inplace_rmw_nontemporal_one_wg_per_16KiB"] = timed(lambda k: diag(0, base[k % pool], 3, 0))
+        ceilings["out_of_place_uint4_copy"] = timed(lambda k: diag(base[k % pool], base[(k + 1) % pool], 0, 8 * cus))
 
     # ---- parity of what was timed: one more launch of the same shape, from pristine frames and a reset seed state, every
     # frame against the oracle (this rank's stripes; rows outside them are not this rank's business and stay zero) ----
@@ -309,7 +317,7 @@ def main():
             roof["copy_ceilings_gbs"] = {k: round(v, 1) for k, v in ceilings.items()}
             plain = max(v for k, v in ceilings.items() if "nontemporal" not in k)
             roof["frac_of_plain_ceiling"] = round(achieved / plain, 4)
-            roof["copy_ceiling_note"] = ("pure streaming kernels (vfgs_hip_diag_stream), same process, same buffers, same bytes per launch, measured right after "
+            roof["copy_ceiling_note"] = ("pure streaming kernels (tools/bench_diag.hip), same process, same buffers, same bytes per launch, measured right after "
                                          "the timed region; copy_ceiling_gbs is the best of them (the nontemporal stream needs line-aligned accesses by waves that "
                                          "live for one 4 KiB item; the grain kernel has the aligned accesses, its waves stream whole rows: DESIGN.md 5), frac_of_plain_ceiling is against the best cached one")
         out = {

@@ -164,13 +164,9 @@ const char* vfgs_hip_last_error_string(void);
 int vfgs_hip_timer_begin(void* stream);
 int vfgs_hip_timer_end(void* stream, float* elapsed_ms);
 
-/* Diagnostics for benchmarks (no grain arithmetic, never called by the library itself): stream `bytes` bytes
- * once through the chip -- mode 0: out-of-place copy src -> dst (16 bytes per lane); mode 1: in-place
- * read-modify-write of dst, persistent waves that move 4 KiB per step (`grid` workgroups of 4 waves, 0 = 8 per CU);
- * mode 2: the same with one workgroup per 16 KiB; mode 3: mode 2 with nontemporal loads and stores (the fastest stream
- * found on gfx950; needs line-aligned wave accesses).  Pointers and size: multiples of 16.  bench.py times these in
- * its own process, on its own buffers, at the grain launch's size, as the copy ceiling of the chip. */
-int vfgs_hip_diag_stream(const void* src, void* dst, uint64_t bytes, int mode, int grid, void* stream);
+/* 1 if this library was built by a developer tool with tuning or ablation knobs (its output may be wrong by design),
+ * 0 for the product build.  versatilefilmgrain_amd/build.py only ever builds the latter. */
+int vfgs_hip_dev_build(void);
 
 /* SURVEY 8f row f3 -- the data path around the reference's yuv_read / yuv_write (yuv.c:162-214): nframes frames that live
  * in HOST memory, processed in place and pipelined through a ring of three device frames: the upload of frame i, the

@@ -109,3 +109,36 @@ def test_host_pipeline_refuses_bad_arguments(hip):
     assert lib.vfgs_hip_add_grain_frames_host(Y, U, V, 1, 416, 64, 400, f.cstride) == 6                # stride < whole blocks
     assert hip.seed_state() == before == ora.seed_state()
     assert np.array_equal(f.Y, keepY)
+
+
+def test_host_pipeline_error_mid_call_drains_what_was_queued(hip):
+    """A failure in the middle of the frame loop (frame 5 of 7 has a null plane pointer) returns the error AFTER the three
+    streams have been drained: the frames queued before it are complete in host memory when the call returns, and the next
+    call finds the ring free."""
+    name = "fgs_sei_10_420"
+    ora, (depth, sx, sy) = program(hip, name)
+    rng = np.random.default_rng(99)
+    fr = []
+    for i in range(7):
+        f = T.Frame(416, 240, depth, sx, sy)
+        for p in f.planes():
+            p[...] = rng.integers(0, 1024, p.shape).astype(f.dtype)
+        fr.append(f)
+    want = [f.copy() for f in fr]
+    for w in want[:5]:
+        ora.add_grain_frame(w)
+    arr = lambda ps: (C.c_void_p * len(ps))(*ps)
+    Y = arr([f.Y.ctypes.data for f in fr[:5]] + [None] + [fr[6].Y.ctypes.data])
+    U = arr([f.U.ctypes.data for f in fr])
+    V = arr([f.V.ctypes.data for f in fr])
+    rc = hip.lib.vfgs_hip_add_grain_frames_host(Y, U, V, 7, 416, 240, fr[0].stride, fr[0].cstride)
+    assert rc == 4
+    for i in range(5):                      # everything queued before the bad frame came home
+        assert fr[i].equal_all(want[i]), i
+    assert fr[6].equal_all(want[6])         # never touched
+    assert hip.seed_state() == ora.seed_state()
+    # the pipeline is usable again right away
+    ora.add_grain_frame(want[6])
+    hip.add_grain_frames_host([fr[6].Y.ctypes.data], [fr[6].U.ctypes.data], [fr[6].V.ctypes.data], 416, 240, fr[0].stride, fr[0].cstride)
+    assert fr[6].equal_all(want[6])
+    assert hip.seed_state() == ora.seed_state()

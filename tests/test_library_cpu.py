@@ -109,3 +109,27 @@ def test_header_is_valid_c_and_links(lib, tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "45 entry points" in r.stdout and "0x00006072" in r.stdout
+
+
+def test_product_library_is_not_a_developer_build(lib):
+    """The shipped library carries every tuning / ablation knob at its default (vfgs_layout.h); the diagnostics of the
+    benchmarks live in a library of their own and are not part of the product ABI."""
+    assert lib.vfgs_hip_dev_build() == 0
+    assert not hasattr(lib, "vfgs_hip_diag_stream")
+    header = (T.ROOT / "include" / "vfgs_hip.h").read_text()
+    assert "diag" not in header
+
+
+@pytest.mark.parametrize("flag", ["-DVFGS_ABLATE=1", "-DVFGS_RW_ABLATE=1", "-DVFGS_WAVES=8", "-DVFGS_NO_ROWWALK", "-DVFGS_LDAUX_ALIGNED=0"])
+def test_a_stray_knob_is_a_build_error(flag, tmp_path):
+    """A -D that changes what the kernels compute (or how) must not produce a product library: without VFGS_DEV_BUILD the
+    layout header refuses it at compile time."""
+    src = tmp_path / "knob.cpp"
+    src.write_text('#include "vfgs_layout.h"\nint main() { return vfgs::kWavesPerWG; }\n')
+    inc = T.ROOT / "versatilefilmgrain_amd" / "csrc"
+    bad = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", f"-I{inc}", flag, str(src)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "VFGS_DEV_BUILD" in bad.stderr
+    ok = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", f"-I{inc}", flag, "-DVFGS_DEV_BUILD", str(src)], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    plain = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", f"-I{inc}", str(src)], capture_output=True, text=True)
+    assert plain.returncode == 0, plain.stderr

@@ -7,6 +7,8 @@ Usage: python tools/ablate.py "0" "1" "0,-DVFGS_WAVES=16,-DVFGS_WG_PER_CU=1" ...
        env ROUNDS (default 5), MODES (default "ip1,ip8": ip = in place, op = out of place, 1/8 = frames per launch)
 """
 import os
+os.environ.setdefault("VFGS_ALLOW_DEV_BUILD", "1")   # this tool builds and loads developer variants
+import os
 import statistics
 import subprocess
 import sys
@@ -34,10 +36,10 @@ def build(variant, tmp):
             src = ROOT / x[4:]
         else:
             flags.append(x)
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-w", f"-DVFGS_ABLATE={parts[0]}",
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-w", "-DVFGS_DEV_BUILD", f"-DVFGS_ABLATE={parts[0]}",
            *flags, f"-I{ROOT / 'versatilefilmgrain_amd/csrc'}", f'-DVFGS_FW_TABLES_PATH="{ROOT / "versatilefilmgrain_amd/csrc/fw_tables.bin"}"',
            "-o", str(out), str(src / "vfgs_kernel.hip"), str(src / "vfgs_host.cpp")]
-    cmd += [str(src / f) for f in ("vfgs_fw_kernel.hip", "vfgs_diag.hip", "vfgs_fw_host.cpp", "vfgs_cfg_host.cpp") if (src / f).exists()]
+    cmd += [str(src / f) for f in ("vfgs_fw_kernel.hip", "vfgs_fw_host.cpp", "vfgs_cfg_host.cpp") if (src / f).exists()]
     subprocess.run(cmd, check=True, cwd=tmp)
     return out
 

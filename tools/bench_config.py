@@ -17,15 +17,15 @@ import vfgs_testlib as T  # noqa: E402
 from versatilefilmgrain_amd import hw  # noqa: E402
 
 CONFIGS = [  # BASELINE.json configs[i]: name, w, h, depth, (subx, suby), trace, kernel
-    ("1920x1080 10-bit 4:2:0 fgs_sei", 1920, 1080, 10, (2, 2), "fgs_sei_10_420", "grain_kernel<10, 2, 2, false>"),
-    ("1920x1080 10-bit 4:2:0 fgs_sei_ff_test1", 1920, 1080, 10, (2, 2), "fgs_sei_ff_test1_10_420", "grain_kernel<10, 2, 2, false>"),
-    ("3840x2160 10-bit 4:2:0 fgs_sei_ar_test1", 3840, 2160, 10, (2, 2), "fgs_sei_ar_test1_10_420", "grain_kernel<10, 2, 2, false>"),
-    ("3840x2160 8-bit 4:4:4 fgs_afgs1_test1", 3840, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", "grain_kernel<8, 1, 1, false>"),
-    ("7680x4320 10-bit 4:2:0 fgs_sei", 7680, 4320, 10, (2, 2), "fgs_sei_10_420", "grain_kernel<10, 2, 2, false>"),
+    ("1920x1080 10-bit 4:2:0 fgs_sei", 1920, 1080, 10, (2, 2), "fgs_sei_10_420", "grain_rw_kernel<10,2,2,...> (row walk; the one-pattern flags depend on the cfg)"),
+    ("1920x1080 10-bit 4:2:0 fgs_sei_ff_test1", 1920, 1080, 10, (2, 2), "fgs_sei_ff_test1_10_420", "grain_rw_kernel<10,2,2,...> (row walk; the one-pattern flags depend on the cfg)"),
+    ("3840x2160 10-bit 4:2:0 fgs_sei_ar_test1", 3840, 2160, 10, (2, 2), "fgs_sei_ar_test1_10_420", "grain_rw_kernel<10,2,2,...> (row walk; the one-pattern flags depend on the cfg)"),
+    ("3840x2160 8-bit 4:4:4 fgs_afgs1_test1", 3840, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", "grain_rw_kernel<8,1,1,...> (row walk; the one-pattern flags depend on the cfg)"),
+    ("7680x4320 10-bit 4:2:0 fgs_sei", 7680, 4320, 10, (2, 2), "fgs_sei_10_420", "grain_rw_kernel<10,2,2,...> (row walk; the one-pattern flags depend on the cfg)"),
     # not BASELINE configs: the everyday formats of the 8-bit paths
-    ("3840x2160 8-bit 4:2:0 fgs_afgs1_test1", 3840, 2160, 8, (2, 2), "fgs_afgs1_test1_8_420", "grain_kernel<8, 2, 2, false>"),
-    ("3840x2160 8-bit 4:2:0 fgs_sei", 3840, 2160, 8, (2, 2), "fgs_sei_8_420", "grain_kernel<8, 2, 2, false>"),
-    ("3840x2160 10-bit 4:2:0 fgs_afgs1_test1", 3840, 2160, 10, (2, 2), "fgs_afgs1_test1_10_420", "grain_kernel<10, 2, 2, false>"),
+    ("3840x2160 8-bit 4:2:0 fgs_afgs1_test1", 3840, 2160, 8, (2, 2), "fgs_afgs1_test1_8_420", "grain_rw_kernel<8,2,2,...> (row walk; the one-pattern flags depend on the cfg)"),
+    ("3840x2160 8-bit 4:2:0 fgs_sei", 3840, 2160, 8, (2, 2), "fgs_sei_8_420", "grain_rw_kernel<8,2,2,...> (row walk; the one-pattern flags depend on the cfg)"),
+    ("3840x2160 10-bit 4:2:0 fgs_afgs1_test1", 3840, 2160, 10, (2, 2), "fgs_afgs1_test1_10_420", "grain_rw_kernel<10,2,2,...> (row walk; the one-pattern flags depend on the cfg)"),
 ]
 
 

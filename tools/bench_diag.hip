@@ -1,4 +1,5 @@
-// Diagnostics, not part of the grain path: pure streaming kernels that move the SAME bytes as a grain
+// Bench-only library (tools/bin/libvfgs_bench_diag.so, built by versatilefilmgrain_amd/build.py next to the product library but
+// NOT part of it, its header or its C ABI): pure streaming kernels that move the SAME bytes as a grain
 // launch (every byte read once and written once) with no arithmetic.  bench.py runs them in its own
 // process, on its own buffers and at its own launch size, and reports the best of them as the copy
 // ceiling of the chip next to the grain kernel's rate ("fraction of peak AND fraction of copy
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void diag_rmw_np_nt(uint8_t* __restrict__ buf,
 
 // mode 0: out-of-place copy src -> dst;  1: in-place read-modify-write of dst, persistent, `grid` workgroups of 4 waves
 // (0 = 8 per CU);  2: in-place, one workgroup per 16 KiB;  3: as 2 with nontemporal loads and stores.  bytes % 16 == 0.
-hipError_t launch_diag_stream(const void* src, void* dst, size_t bytes, int mode, int grid, int cu_count, hipStream_t stream)
+static hipError_t launch_diag_stream(const void* src, void* dst, size_t bytes, int mode, int grid, int cu_count, hipStream_t stream)
 {
 	const size_t n = bytes / 16;
 	if (n == 0) return hipSuccess;
@@ -91,3 +92,11 @@ hipError_t launch_diag_stream(const void* src, void* dst, size_t bytes, int mode
 }
 
 }  // namespace vfgs
+
+// C entry for bench.py (ctypes): 0 or a hipError_t.  Pointers and size: multiples of 16 bytes.
+extern "C" int vfgs_bench_diag_stream(const void* src, void* dst, uint64_t bytes, int mode, int grid, int cu_count, void* stream)
+{
+	if (((uintptr_t)src | (uintptr_t)dst | bytes) & 15) return (int)hipErrorInvalidValue;
+	if (mode < 0 || mode > 3 || !dst || (mode == 0 && !src)) return (int)hipErrorInvalidValue;
+	return (int)vfgs::launch_diag_stream(src, dst, (size_t)bytes, mode, grid, cu_count, (hipStream_t)stream);
+}

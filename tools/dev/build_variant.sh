@@ -5,5 +5,5 @@ cd "$(dirname "$0")/../.." || exit 1
 C=versatilefilmgrain_amd/csrc
 name=$1; shift
 mkdir -p tools/bin
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -w "$@" -DVFGS_FW_TABLES_PATH="\"$PWD/$C/fw_tables.bin\"" \
-  -o tools/bin/$name.so $C/vfgs_kernel.hip $C/vfgs_fw_kernel.hip $C/vfgs_diag.hip $C/vfgs_host.cpp $C/vfgs_fw_host.cpp $C/vfgs_cfg_host.cpp && echo built tools/bin/$name.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -w -DVFGS_DEV_BUILD "$@" -DVFGS_FW_TABLES_PATH="\"$PWD/$C/fw_tables.bin\"" \
+  -o tools/bin/$name.so $C/vfgs_kernel.hip $C/vfgs_fw_kernel.hip $C/vfgs_host.cpp $C/vfgs_fw_host.cpp $C/vfgs_cfg_host.cpp && echo built tools/bin/$name.so

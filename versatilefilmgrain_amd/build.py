@@ -14,7 +14,10 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libvfgs_hip.so"
-SOURCES = [CSRC / "vfgs_kernel.hip", CSRC / "vfgs_fw_kernel.hip", CSRC / "vfgs_diag.hip", CSRC / "vfgs_host.cpp", CSRC / "vfgs_fw_host.cpp", CSRC / "vfgs_cfg_host.cpp"]
+SOURCES = [CSRC / "vfgs_kernel.hip", CSRC / "vfgs_fw_kernel.hip", CSRC / "vfgs_host.cpp", CSRC / "vfgs_fw_host.cpp", CSRC / "vfgs_cfg_host.cpp"]
+# bench-only streaming kernels (the copy ceiling bench.py reports): a library of their own, outside the product and its ABI
+DIAG_SRC = PKG.parent / "tools" / "bench_diag.hip"
+DIAG_LIB = PKG.parent / "tools" / "bin" / "libvfgs_bench_diag.so"
 FW_TABLES = CSRC / "fw_tables.bin"   # model constants, linked into the library as data (oracle/dump_fw_tables.c)
 HEADERS = [CSRC / "vfgs_layout.h", CSRC / "vfgs_fw_layout.h", FW_TABLES,
            PKG.parent / "include" / "vfgs_hip.h", PKG.parent / "include" / "vfgs_hip_fw.h"]
@@ -35,11 +38,27 @@ def up_to_date() -> bool:
     return all(p.stat().st_mtime <= t for p in SOURCES + HEADERS)
 
 
+def build_diag(force: bool = False) -> Path:
+    if DIAG_LIB.exists() and DIAG_LIB.stat().st_mtime >= DIAG_SRC.stat().st_mtime and not force:
+        return DIAG_LIB
+    DIAG_LIB.parent.mkdir(parents=True, exist_ok=True)
+    r = subprocess.run([hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", str(DIAG_LIB), str(DIAG_SRC)],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+    return DIAG_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
+    build_diag(force)
     if up_to_date() and not force:
         return LIB
     with tempfile.TemporaryDirectory(prefix="vfgs_build_") as tmp:
         out = Path(tmp) / LIB.name
+        # (no -D beyond the tables path: vfgs_layout.h refuses any tuning / ablation knob without VFGS_DEV_BUILD, and
+        # HIPCC_COMPILE_FLAGS_APPEND could smuggle one in)
+        if "VFGS_" in os.environ.get("HIPCC_COMPILE_FLAGS_APPEND", ""):
+            raise RuntimeError("HIPCC_COMPILE_FLAGS_APPEND carries a VFGS_ flag: the product build takes none")
         cmd = [hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
                "-Wall", "-Wno-unused-function", f'-DVFGS_FW_TABLES_PATH="{FW_TABLES}"',
                "-o", str(out)] + [str(s) for s in SOURCES]

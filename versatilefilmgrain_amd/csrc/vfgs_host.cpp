@@ -28,7 +28,6 @@ bool aligned_ok(int depth, int csubx, int nblk, bool out8);
 bool rowwalk_ok(int depth, int csubx, int nblk, bool out8);
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
 void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes);
-hipError_t launch_diag_stream(const void* src, void* dst, size_t bytes, int mode, int grid, int cu_count, hipStream_t stream);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
 hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby,
                            bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, hipStream_t stream);
@@ -1002,34 +1001,41 @@ int run_host_frames(void* const* Y, void* const* U, void* const* V, unsigned nfr
 		}
 	}
 	int rc = 0;
+	// (no early return below: whatever happens, the three streams are drained before the call returns -- copies into the
+	// caller's memory may be in flight)
+	auto hip = [&](hipError_t e, const char* what) {
+		if (e != hipSuccess && !rc) rc = fail((int)e, "%s -> %s (vfgs_hip_add_grain_frames_host)", what, hipGetErrorString(e));
+		return e == hipSuccess;
+	};
 	for (unsigned f = 0; f < nframes && !rc; f++)
 	{
 		const int k = (int)(f % D);
 		void* host[3] = {Y[f], U[f], V[f]};
 		if (!host[0] || !host[1] || !host[2]) { rc = fail(4, "vfgs_hip_add_grain_frames_host: null plane pointer in frame %u", f); break; }
-		if (P.busy[k]) { HIP_TRY(hipEventSynchronize(P.down_done[k])); P.busy[k] = false; }   // the slot's previous frame is back in host memory
-		for (int i = 0; i < 3; i++)
+		if (P.busy[k]) { if (!hip(hipEventSynchronize(P.down_done[k]), "hipEventSynchronize")) break; P.busy[k] = false; }   // the slot's previous frame is back in host memory
+		bool ok = true;
+		for (int i = 0; i < 3 && ok; i++)
 		{
 			const size_t need = (size_t)dpitch[i] * rows[i] + 256;
 			if (P.cap[k][i] < need)
 			{
-				if (P.dev[k][i]) HIP_TRY(hipFree(P.dev[k][i]));
+				if (P.dev[k][i]) (void)hipFree(P.dev[k][i]);
 				P.dev[k][i] = nullptr; P.cap[k][i] = 0;
-				HIP_TRY(hipMalloc(&P.dev[k][i], need));
-				P.cap[k][i] = need;
+				ok = hip(hipMalloc(&P.dev[k][i], need), "hipMalloc");
+				if (ok) P.cap[k][i] = need;
 			}
-			HIP_TRY(hipMemcpy2DAsync(P.dev[k][i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, P.up));
+			ok = ok && hip(hipMemcpy2DAsync(P.dev[k][i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, P.up), "hipMemcpy2DAsync (upload)");
 		}
-		HIP_TRY(hipEventRecord(P.up_done[k], P.up));
-		HIP_TRY(hipStreamWaitEvent(P.run, P.up_done[k], 0));
+		if (!ok) break;
+		if (!hip(hipEventRecord(P.up_done[k], P.up), "hipEventRecord") || !hip(hipStreamWaitEvent(P.run, P.up_done[k], 0), "hipStreamWaitEvent")) break;
 		rc = run_device(P.dev[k][0], P.dev[k][1], P.dev[k][2], P.dev[k][0], P.dev[k][1], P.dev[k][2], width, 0, height, 0, height,
 		                dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, P.run);
 		if (rc) break;
-		HIP_TRY(hipEventRecord(P.run_done[k], P.run));
-		HIP_TRY(hipStreamWaitEvent(P.down, P.run_done[k], 0));
-		for (int i = 0; i < 3; i++)
-			HIP_TRY(hipMemcpy2DAsync(host[i], spitch[i], P.dev[k][i], dpitch[i], rowlen[i], rows[i], hipMemcpyDeviceToHost, P.down));
-		HIP_TRY(hipEventRecord(P.down_done[k], P.down));
+		if (!hip(hipEventRecord(P.run_done[k], P.run), "hipEventRecord") || !hip(hipStreamWaitEvent(P.down, P.run_done[k], 0), "hipStreamWaitEvent")) break;
+		for (int i = 0; i < 3 && ok; i++)
+			ok = hip(hipMemcpy2DAsync(host[i], spitch[i], P.dev[k][i], dpitch[i], rowlen[i], rows[i], hipMemcpyDeviceToHost, P.down), "hipMemcpy2DAsync (download)");
+		if (!ok) break;
+		if (!hip(hipEventRecord(P.down_done[k], P.down), "hipEventRecord")) break;
 		P.busy[k] = true;
 	}
 	// everything queued so far comes home before the call returns, also after an error
@@ -1604,14 +1610,13 @@ int vfgs_hip_timer_end(void* stream, float* elapsed_ms)
 	return 0;
 }
 
-int vfgs_hip_diag_stream(const void* src, void* dst, uint64_t bytes, int mode, int grid, void* stream)
+int vfgs_hip_dev_build(void)
 {
-	std::lock_guard<std::mutex> g(g_mu);
-	if (int e = ensure_init(-1)) return e;
-	if (((uintptr_t)src | (uintptr_t)dst | bytes) & 15) return fail(7, "vfgs_hip_diag_stream: pointers and size must be multiples of 16 bytes");
-	if (mode < 0 || mode > 3 || !dst || (mode == 0 && !src)) return fail(25, "vfgs_hip_diag_stream: mode %d", mode);
-	HIP_TRY(vfgs::launch_diag_stream(src, dst, (size_t)bytes, mode, grid, S().cu_count, (hipStream_t)stream));
+#ifdef VFGS_DEV_BUILD
+	return 1;      // built by a developer tool with tuning / ablation knobs: results may be wrong by design
+#else
 	return 0;
+#endif
 }
 
 int vfgs_hip_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* name, int name_len)

@@ -857,7 +857,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	constexpr int STEP = kWavesPerWG * 64 * 16;
 	constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
 	u32x4 tmp[NIT];
-#if defined(VFGS_RW_ABLATE) && VFGS_RW_ABLATE >= 2
+#if VFGS_RW_ABLATE >= 2
 #pragma unroll
 	for (int it = 0; it < NIT; it++) tmp[it] = u32x4{1, 2, 3, 4};
 #else
@@ -879,7 +879,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 		{
 			const int e = (int)threadIdx.x + i * kWavesPerWG * 64;
 			const uint32_t blk = (uint32_t)min(max(e - 1, 0), last);
-#if defined(VFGS_RW_ABLATE) && VFGS_RW_ABLATE >= 3
+#if VFGS_RW_ABLATE >= 3
 			const bool need = false;
 #else
 			const bool need = e < a.nblk + 4 && e < kParamEntries;
@@ -908,7 +908,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 #pragma unroll
 		for (int u = 0; u < 4; u++) load_seg<LDA>(rs0, lane16 + u * (kMaxUnits * 16), 0, w[u]);
 	}
-#if !(defined(VFGS_RW_ABLATE) && VFGS_RW_ABLATE >= 2)
+#if VFGS_RW_ABLATE < 2
 #pragma unroll
 	for (int it = 0; it < NIT; it++)
 		*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
@@ -993,7 +993,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 				for (int d = K; d < 4; d++) asm volatile("v_mov_b32 %0, %1" : "=v"(t[d]) : "v"(w[u][d - K]));
 				// the registers are free: refill them with the segment four steps ahead
 				load_seg<LDA>(nsrc, lane16 + u * (kMaxUnits * 16), 0, w[u]);
-#if defined(VFGS_RW_ABLATE) && VFGS_RW_ABLATE >= 1       // timing experiments only (tools/dev/build_variant.sh): copy, WRONG output
+#if VFGS_RW_ABLATE >= 1       // timing experiments only (tools/dev/build_variant.sh): copy, WRONG output
 				if (false)
 #else
 				if (4 * g + u < tsegs)

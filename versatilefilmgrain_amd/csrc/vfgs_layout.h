@@ -62,6 +62,23 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #define VFGS_RW_CONSEC 0      // row walk: 1 = a wave's rows are consecutive, 0 = the waves of a workgroup take every kWavesPerWG-th row
 #endif
 
+#ifndef VFGS_RW_ABLATE
+#define VFGS_RW_ABLATE 0      // row-walk kernels: 0 = product; 1..3 timing-only variants with WRONG output (tools/dev/build_variant.sh)
+#endif
+
+// The product is built with every knob at its default (versatilefilmgrain_amd/build.py passes none).  The developer tools that
+// time variants (tools/dev/build_variant.sh, tools/gpu_variants.sh, tools/ablate.py) define VFGS_DEV_BUILD; without it any
+// other value is a build error, so a stray -D cannot produce a library that silently computes something else -- and a
+// developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
+#if !defined(VFGS_DEV_BUILD)
+#if VFGS_WAVES != 4 || VFGS_ROWS_PER_WAVE != 4 || VFGS_WG_PER_CU != 4 || VFGS_WG_PER_CU_8BIT_SUB != 3 || VFGS_LDAUX != 0 || VFGS_STAUX != 0 || \
+    VFGS_PREFETCH != 1 || VFGS_SCHED_FENCE != 1 || VFGS_SPLIT_INTERLEAVE != 0 || VFGS_ABLATE != 0 || VFGS_ALIGNED != 1 || VFGS_LANE_SHIFT_DPP != 1 || \
+    VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || VFGS_RW_ABLATE != 0 || defined(VFGS_NO_ROWWALK) || \
+    defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_ALIGN_TEST)
+#error "libvfgs_hip: a tuning / ablation knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
+#endif
+#endif
+
 constexpr int kWavesPerWG = VFGS_WAVES;
 constexpr int kRowsPerWave = VFGS_ROWS_PER_WAVE;
 

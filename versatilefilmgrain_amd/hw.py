@@ -8,6 +8,7 @@ a namespace around that singleton, not an object with private state.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 from .build import LIB
@@ -58,7 +59,6 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_timer_begin.argtypes = [vp]
     lib.vfgs_hip_timer_end.argtypes = [vp, C.POINTER(C.c_float)]
     lib.vfgs_hip_device_info.argtypes = [C.POINTER(i), C.POINTER(i), C.POINTER(i), C.c_char_p, i]
-    lib.vfgs_hip_diag_stream.argtypes = [vp, vp, C.c_uint64, i, i, vp]
     lib.vfgs_hip_line_lookahead.argtypes = [i]
     lib.vfgs_hip_line_lookahead.restype = None
     lib.vfgs_hip_declare_frame.argtypes = [vp, vp, vp, u, u, u, u]
@@ -67,6 +67,9 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_host_alloc.restype = vp
     lib.vfgs_hip_host_free.argtypes = [vp]
     lib.vfgs_hip_host_free.restype = None
+    # a library built by a developer tool with tuning / ablation knobs may compute something else by design: only on request
+    if lib.vfgs_hip_dev_build() and not os.environ.get("VFGS_ALLOW_DEV_BUILD"):
+        raise VfgsHipError(f"{path} is a developer build (tuning / ablation knobs); set VFGS_ALLOW_DEV_BUILD=1 to load it anyway")
     _lib = lib
     return lib
 
@@ -82,7 +85,7 @@ EXPORTS = [
     "vfgs_hip_add_grain_frames_dev", "vfgs_hip_add_grain_frames_part_dev", "vfgs_hip_add_grain_copy_dev",
     "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
-    "vfgs_hip_diag_stream", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
+    "vfgs_hip_dev_build", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
     "vfgs_hip_add_grain_frames_host", "vfgs_hip_host_alloc", "vfgs_hip_host_free",
 ]
 
@@ -191,10 +194,6 @@ class VfgsHip:
 
     def host_free(self, p):
         self.lib.vfgs_hip_host_free(p)
-
-    def diag_stream(self, src, dst, nbytes, mode, grid=0, stream=0):
-        """Pure streaming kernels (no grain arithmetic): the copy ceiling of the chip, for bench.py."""
-        self._ck(self.lib.vfgs_hip_diag_stream(src, dst, nbytes, mode, grid, stream))
 
     def device_info(self):
         cu, lds, clk = C.c_int(), C.c_int(), C.c_int()
