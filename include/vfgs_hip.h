@@ -164,6 +164,15 @@ const char* vfgs_hip_last_error_string(void);
 int vfgs_hip_timer_begin(void* stream);
 int vfgs_hip_timer_end(void* stream, float* elapsed_ms);
 
+/* Several devices in ONE process, for frames that live in host memory (SURVEY 8e x 8f row f3; the reference's frame loop and
+ * file I/O, vfgs_main.c:664-682 / yuv.c:162-214, are one process and one thread).  After this call vfgs_add_grain_stripe and
+ * vfgs_hip_add_grain_frames_host give every listed device a stripe of whole 16-line block rows of each frame and run the
+ * devices concurrently (one PCIe link each, no exchange between them); results and seed registers are those of the
+ * single-device call.  devices[0] is the library's device for everything else (the device-pointer entry points, the line
+ * call).  A device may be listed more than once (testing on a one-GPU machine).  n = 1 returns to one device.
+ * 0 or an error code. */
+int vfgs_hip_init_devices(const int* devices, int n);
+
 /* 1 if this library was built by a developer tool with tuning or ablation knobs (its output may be wrong by design),
  * 0 for the product build.  versatilefilmgrain_amd/build.py only ever builds the latter. */
 int vfgs_hip_dev_build(void);

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vfgs_hip.h"
@@ -276,6 +277,7 @@ public:
 	// before every kernel launch on `stream` that reads the current slot
 	hipError_t use(hipStream_t stream) { return cur_ < 0 ? hipSuccess : slot_[cur_].guard.use(stream); }
 
+	uint32_t seed_reg() const { return seed_reg_; }
 	const uint32_t* dev() const { return cur_ < 0 ? nullptr : slot_[cur_].dev; }
 	uint64_t base_bit() const { return cur_ < 0 ? 0 : slot_[cur_].wbase << 5; }
 	uint64_t dev_words() const { return cur_ < 0 ? 0 : slot_[cur_].nwords; }
@@ -424,6 +426,11 @@ struct State {
 	hipEvent_t bank_ev = nullptr;             // ... and their completion, for the (rare) change of stream
 	bool bank_used = false;
 
+	// ---- several devices in one process (vfgs_hip_init_devices): states 1.. are replicas of state 0 --------------
+	uint64_t prog_gen = 0;            // bumped whenever the programmed state (banks, LUTs, parameters, patterns) may have changed
+	uint64_t seed_epoch = 0;          // bumped whenever the LFSR is reloaded
+	uint64_t synced_prog = ~0ull, synced_seed = ~0ull;   // replica: what of the primary it mirrors
+
 	// ---- look-ahead of the line API (see line_call()) -----------------------------------
 	uint64_t gen = 0;                 // bumped by every call that changes state other than a line call
 	struct LineAhead {
@@ -456,10 +463,17 @@ struct State {
 	}
 };
 
+// State 0 is the reference's process-global hardware layer.  After vfgs_hip_init_devices() states 1..n-1 are replicas bound to
+// the other devices: the host-memory entry points give every device a stripe of each frame and run them concurrently, one
+// worker thread per extra device, each with ITS state current (g_cur).  Everything else only ever sees state 0.
+constexpr int kMaxDevices = 8;
+State g_states[kMaxDevices];
+thread_local State* g_cur = nullptr;
+int g_ndev = 1;
+
 State& S()
 {
-	static State s;
-	return s;
+	return g_cur ? *g_cur : g_states[0];
 }
 
 std::mutex g_mu;
@@ -612,6 +626,7 @@ int fw_generate(const vfgs_hip_pattern_job* jobs, int n)
 	}
 	for (int i = 0; i < n; i++) s.dev_origin[jobs[i].chroma ? 1 : 0] |= 1u << jobs[i].index;
 	s.tables_dirty = true;
+	s.prog_gen++;
 	return 0;
 }
 
@@ -921,23 +936,33 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 }
 
 // host-memory stripe: stage through device buffers (compatibility path of the line API)
-int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride)
+// Lines [y, y + height) are the call's stripe (the seed registers advance over all of them); lines [py, py + ph) inside it are
+// the part THIS state's device processes (the whole stripe unless several devices share it).  Y/U/V address line y.
+int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride, unsigned py, unsigned ph)
 {
 	State& s = S();
 	if (int e = ensure_init(-1)) return e;
 	if (height == 0) return 0;
 	const unsigned sz = s.bs ? 2 : 1;
 	const unsigned nblk = (width + 15) / 16;
-	// rows of each plane touched by lines [y, y+height)
-	const unsigned crow0 = y / s.csuby;
-	const unsigned crows = (y + height - 1) / s.csuby - crow0 + 1;
-	const unsigned rows[3] = {height, crows, crows};
+	if (ph == 0)
+	{
+		// nothing of this stripe is mine: the registers still move (vfgs_hw.c:291-298, 309-310)
+		if (int e = check_luts(s)) return e;
+		advance_seeds(s, y, height, nblk, y);
+		return 0;
+	}
+	// rows of each plane touched by lines [py, py+ph)
+	const unsigned crow0 = py / s.csuby;
+	const unsigned crows = (py + ph - 1) / s.csuby - crow0 + 1;
+	const unsigned rows[3] = {ph, crows, crows};
 	const unsigned rowlen[3] = {nblk * 16 * sz, nblk * 16 / s.csubx * sz, nblk * 16 / s.csubx * sz};  // bytes the reference touches per row
 	const unsigned dpitch[3] = {(rowlen[0] + 255) & ~255u, (rowlen[1] + 255) & ~255u, (rowlen[2] + 255) & ~255u};
 	// (a 1-line stripe from vfgs_add_grain_line carries no pitch; it needs none)
 	const size_t spitch[3] = {std::max<size_t>((size_t)stride * sz, rowlen[0]), std::max<size_t>((size_t)cstride * sz, rowlen[1]),
 	                          std::max<size_t>((size_t)cstride * sz, rowlen[2])};
-	void* host[3] = {Y, U, V};
+	uint8_t* host[3] = {(uint8_t*)Y + (size_t)(py - y) * spitch[0], (uint8_t*)U + (size_t)(crow0 - y / s.csuby) * spitch[1],
+	                    (uint8_t*)V + (size_t)(crow0 - y / s.csuby) * spitch[2]};
 	for (int i = 0; i < 3; i++)
 	{
 		const size_t need = (size_t)dpitch[i] * rows[i] + 256;
@@ -950,13 +975,18 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 		}
 		HIP_TRY(hipMemcpy2DAsync(s.stage[i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, s.own_stream));
 	}
-	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], s.stage[0], s.stage[1], s.stage[2], width, y, height, y, height,
+	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], s.stage[0], s.stage[1], s.stage[2], width, y, height, py, ph,
 	                       dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, s.own_stream))
 		return e;
 	for (int i = 0; i < 3; i++)
 		HIP_TRY(hipMemcpy2DAsync(host[i], spitch[i], s.stage[i], dpitch[i], rowlen[i], rows[i], hipMemcpyDeviceToHost, s.own_stream));
 	HIP_TRY(hipStreamSynchronize(s.own_stream));
 	return 0;
+}
+
+int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride)
+{
+	return run_host(Y, U, V, y, width, height, stride, cstride, y, height);
 }
 
 // ------------------------------------------------------------------------------------
@@ -967,8 +997,9 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 // With pinned host memory (vfgs_hip_host_alloc) the copies are asynchronous; pageable memory works, the runtime then
 // stages every copy itself and the calling thread blocks for it.  The seed registers advance frame by frame exactly as
 // with nframes calls of the frame entry point.
+// (py, ph: the lines of every frame THIS state's device processes -- the whole frame unless several devices share the frames)
 int run_host_frames(void* const* Y, void* const* U, void* const* V, unsigned nframes, unsigned width, unsigned height,
-                    unsigned stride, unsigned cstride)
+                    unsigned stride, unsigned cstride, unsigned py, unsigned ph)
 {
 	State& s = S();
 	if (int e = ensure_init(-1)) return e;
@@ -981,8 +1012,14 @@ int run_host_frames(void* const* Y, void* const* U, void* const* V, unsigned nfr
 	constexpr int D = State::HostPipe::kDepth;
 	const unsigned sz = s.bs ? 2 : 1;
 	const unsigned nblk = (width + 15) / 16;
-	const unsigned crows = (height - 1) / s.csuby + 1;
-	const unsigned rows[3] = {height, crows, crows};
+	if (ph == 0)
+	{
+		for (unsigned f = 0; f < nframes; f++) advance_seeds(s, 0, height, nblk, 0);   // nothing of the frames is mine: the registers still move
+		return 0;
+	}
+	const unsigned crow0 = py / s.csuby;
+	const unsigned crows = (py + ph - 1) / s.csuby - crow0 + 1;
+	const unsigned rows[3] = {ph, crows, crows};
 	const unsigned rowlen[3] = {nblk * 16 * sz, nblk * 16 / s.csubx * sz, nblk * 16 / s.csubx * sz};
 	if ((size_t)stride * sz < rowlen[0] || (size_t)cstride * sz < rowlen[1])
 		return fail(6, "stride too small: every row must hold whole 16-sample blocks (vfgs_hw.c:301)");
@@ -1010,8 +1047,8 @@ int run_host_frames(void* const* Y, void* const* U, void* const* V, unsigned nfr
 	for (unsigned f = 0; f < nframes && !rc; f++)
 	{
 		const int k = (int)(f % D);
-		void* host[3] = {Y[f], U[f], V[f]};
-		if (!host[0] || !host[1] || !host[2]) { rc = fail(4, "vfgs_hip_add_grain_frames_host: null plane pointer in frame %u", f); break; }
+		if (!Y[f] || !U[f] || !V[f]) { rc = fail(4, "vfgs_hip_add_grain_frames_host: null plane pointer in frame %u", f); break; }
+		uint8_t* host[3] = {(uint8_t*)Y[f] + (size_t)py * spitch[0], (uint8_t*)U[f] + (size_t)crow0 * spitch[1], (uint8_t*)V[f] + (size_t)crow0 * spitch[2]};
 		if (P.busy[k]) { if (!hip(hipEventSynchronize(P.down_done[k]), "hipEventSynchronize")) break; P.busy[k] = false; }   // the slot's previous frame is back in host memory
 		bool ok = true;
 		for (int i = 0; i < 3 && ok; i++)
@@ -1028,7 +1065,7 @@ int run_host_frames(void* const* Y, void* const* U, void* const* V, unsigned nfr
 		}
 		if (!ok) break;
 		if (!hip(hipEventRecord(P.up_done[k], P.up), "hipEventRecord") || !hip(hipStreamWaitEvent(P.run, P.up_done[k], 0), "hipStreamWaitEvent")) break;
-		rc = run_device(P.dev[k][0], P.dev[k][1], P.dev[k][2], P.dev[k][0], P.dev[k][1], P.dev[k][2], width, 0, height, 0, height,
+		rc = run_device(P.dev[k][0], P.dev[k][1], P.dev[k][2], P.dev[k][0], P.dev[k][1], P.dev[k][2], width, 0, height, py, ph,
 		                dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, P.run);
 		if (rc) break;
 		if (!hip(hipEventRecord(P.run_done[k], P.run), "hipEventRecord") || !hip(hipStreamWaitEvent(P.down, P.run_done[k], 0), "hipStreamWaitEvent")) break;
@@ -1211,6 +1248,135 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 	return rc;
 }
 
+// ------------------------------------------------------------------------------------
+// Several devices in one process (vfgs_hip_init_devices): the reference's API is one process-global hardware layer driven by
+// one thread (vfgs_main.c:664-682), so a frame that lives in HOST memory can only use one PCIe link -- unless the library
+// splits it.  Replicas of the programmed state are kept for the other devices; the host-memory entry points hand every
+// device a stripe of whole 16-line block rows of each frame (no halo, no exchange: SURVEY 8e) and run the devices
+// concurrently, one worker thread per extra device.  Every state advances the seed registers over the WHOLE stripe or
+// frame, exactly like the ranks of bench.py, so all of them stay in step without talking to each other.
+
+// bring replica r (current state of the calling thread, its device current) in line with primary p
+int sync_replica(State& r, State& p)
+{
+	if (r.synced_prog != p.prog_gen)
+	{
+		bool changed = memcmp(r.bank, p.bank, sizeof r.bank) || memcmp(r.slut, p.slut, sizeof r.slut) || memcmp(r.plut, p.plut, sizeof r.plut) ||
+		               r.scale_shift != p.scale_shift || r.bs != p.bs || r.ymin != p.ymin || r.ymax != p.ymax || r.cmin != p.cmin ||
+		               r.cmax != p.cmax || r.csubx != p.csubx || r.csuby != p.csuby || r.dev_origin[0] != p.dev_origin[0] ||
+		               r.dev_origin[1] != p.dev_origin[1];
+		memcpy(r.bank, p.bank, sizeof r.bank); memcpy(r.slut, p.slut, sizeof r.slut); memcpy(r.plut, p.plut, sizeof r.plut);
+		r.scale_shift = p.scale_shift; r.bs = p.bs; r.ymin = p.ymin; r.ymax = p.ymax; r.cmin = p.cmin; r.cmax = p.cmax;
+		r.csubx = p.csubx; r.csuby = p.csuby;
+		r.dev_origin[0] = p.dev_origin[0]; r.dev_origin[1] = p.dev_origin[1];
+		r.fw_pending.clear(); r.fw_last_valid = false;
+		if (p.dev_origin[0] | p.dev_origin[1])
+		{
+			// patterns generated on the primary's device never visit the host: copy its banks (64 KiB; the dispatcher has
+			// flushed and drained the primary's generation kernels before the workers start)
+			if (int e = fw_prepare(r)) return e;
+			if (int e = fw_bank_stream(r, r.own_stream)) return e;
+			HIP_TRY(hipMemcpyAsync(r.dev_bank, p.dev_bank, 2 * vfgs::kSlots * 4096, hipMemcpyDefault, r.own_stream));
+			HIP_TRY(hipStreamSynchronize(r.own_stream));
+			changed = true;
+		}
+		if (changed) r.tables_dirty = true;
+		r.synced_prog = p.prog_gen;
+	}
+	if (r.synced_seed != p.seed_epoch)
+	{
+		r.lfsr.reseed(p.lfsr.seed_reg());
+		r.synced_seed = p.seed_epoch;
+	}
+	r.rnd = p.rnd; r.rnd_up = p.rnd_up; r.line_rnd = p.line_rnd; r.line_rnd_up = p.line_rnd_up;
+	return 0;
+}
+
+// lines [y, y + height) -> n parts of whole block rows, sizes differing by at most one block row
+void split_lines(unsigned y, unsigned height, int n, int d, unsigned* py, unsigned* ph)
+{
+	const unsigned br0 = y >> 4, nbr = ((y + height - 1) >> 4) - br0 + 1;
+	const unsigned base = nbr / n, extra = nbr % n;
+	const unsigned first = br0 + d * base + std::min<unsigned>(d, extra), count = base + ((unsigned)d < extra ? 1 : 0);
+	const unsigned lo = std::max(y, first * 16), hi = std::min(y + height, (first + count) * 16);
+	*py = count ? lo : y;
+	*ph = (count && hi > lo) ? hi - lo : 0;
+}
+
+// run fn(d) for every device, state d current on the thread that runs it; device 0 on the calling thread
+template <class F>
+int on_all_devices(F&& fn)
+{
+	State& p = g_states[0];
+	if (int e = ensure_init(-1)) return e;
+	if (p.dev_origin[0] | p.dev_origin[1])
+	{
+		// device-generated patterns: have them finished before the replicas copy them
+		bool stale = false;
+		for (int d = 1; d < g_ndev; d++) stale = stale || g_states[d].synced_prog != p.prog_gen;
+		if (stale)
+		{
+			if (int e = fw_flush(p, p.own_stream)) return e;
+			if (int e = fw_bank_stream(p, p.own_stream)) return e;
+			HIP_TRY(hipStreamSynchronize(p.own_stream));
+		}
+	}
+	// the replicas take over the primary's programming and seed registers BEFORE anything runs: the primary's own part
+	// advances those registers
+	for (int d = 1; d < g_ndev; d++)
+	{
+		g_cur = &g_states[d];
+		int e = ensure_init(-1);
+		if (!e) e = sync_replica(g_states[d], p);
+		g_cur = nullptr;
+		if (e) { (void)hipSetDevice(p.device); return e; }
+	}
+	HIP_TRY(hipSetDevice(p.device));
+	int rc[kMaxDevices] = {};
+	std::string msg[kMaxDevices];
+	auto body = [&](int d) {
+		g_cur = &g_states[d];
+		int e = ensure_init(-1);
+		if (!e) e = fn(d);
+		rc[d] = e;
+		if (e) msg[d] = g_errstr;
+		g_cur = nullptr;
+	};
+	std::vector<std::thread> workers;
+	for (int d = 1; d < g_ndev; d++) workers.emplace_back(body, d);
+	body(0);
+	for (std::thread& t : workers) t.join();
+	for (int d = 0; d < g_ndev; d++)
+		if (rc[d]) return fail(rc[d], "device %d of %d: %s", d, g_ndev, msg[d].c_str());
+	return 0;
+}
+
+int run_host_multi(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride)
+{
+	// a stripe of less than one block row per device is not worth the threads (and a 1-line call has no pitch to split by)
+	if (g_ndev == 1 || height < 16u * g_ndev)
+		return run_host(Y, U, V, y, width, height, stride, cstride);
+	return on_all_devices([&](int d) {
+		unsigned py, ph;
+		split_lines(y, height, g_ndev, d, &py, &ph);
+		return run_host(Y, U, V, y, width, height, stride, cstride, py, ph);
+	});
+}
+
+int run_host_frames_multi(void* const* Y, void* const* U, void* const* V, unsigned nframes, unsigned width, unsigned height,
+                          unsigned stride, unsigned cstride)
+{
+	if (g_ndev == 1 || height < 16u * g_ndev)
+		return run_host_frames(Y, U, V, nframes, width, height, stride, cstride, 0, height);
+	return on_all_devices([&](int d) {
+		unsigned py, ph;
+		split_lines(0, height, g_ndev, d, &py, &ph);
+		return run_host_frames(Y, U, V, nframes, width, height, stride, cstride, py, ph);
+	});
+}
+
+void release_state(State& s);
+
 }  // namespace
 
 namespace vfgs {
@@ -1218,182 +1384,9 @@ namespace vfgs {
 int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 }
 
-// ========================================================================================
-// C ABI
-
-extern "C" {
-
-void vfgs_set_luma_pattern(int index, signed char* P)
+namespace {
+void release_state_impl(State& s)
 {
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_luma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:316)"); }
-	State& s = S();
-	const bool host_slot = !(s.dev_origin[0] >> index & 1);
-	if (host_slot && !memcmp(s.bank[0][index], P, 64 * 64)) return;   // unchanged: the device image stays valid
-	memcpy(s.bank[0][index], P, 64 * 64);   // vfgs_hw.c:317
-	s.dev_origin[0] &= ~(1u << index);
-	s.tables_dirty = true;
-}
-
-void vfgs_set_chroma_pattern(int index, signed char* P)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	State& s = S();
-	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_chroma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:322)"); }
-	bool same = !(s.dev_origin[1] >> index & 1);
-	for (int i = 0; i < 64 / s.csuby && same; i++)
-		same = !memcmp(s.bank[1][index][i], P + (64 / s.csuby) * i, 64 / s.csubx);
-	if (same) return;                        // unchanged: the device image stays valid
-	for (int i = 0; i < 64 / s.csuby; i++)   // vfgs_hw.c:323-324: pitch from csuby, length from csubx
-		memcpy(s.bank[1][index][i], P + (64 / s.csuby) * i, 64 / s.csubx);
-	s.dev_origin[1] &= ~(1u << index);
-	s.tables_dirty = true;
-}
-
-void vfgs_set_scale_lut(int c, unsigned char lut[])
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	if (c < 0 || c > 2) { fail(21, "vfgs_set_scale_lut: component %d", c); die("bad component (vfgs_hw.c:329)"); }
-	if (!memcmp(S().slut[c], lut, 256)) return;   // unchanged (e.g. the same model re-sent with a new seed): nothing to upload
-	memcpy(S().slut[c], lut, 256);
-	S().tables_dirty = true;
-}
-
-void vfgs_set_pattern_lut(int c, unsigned char lut[])
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	if (c < 0 || c > 2) { fail(21, "vfgs_set_pattern_lut: component %d", c); die("bad component (vfgs_hw.c:335)"); }
-	if (!memcmp(S().plut[c], lut, 256)) return;
-	memcpy(S().plut[c], lut, 256);
-	S().tables_dirty = true;
-}
-
-void vfgs_set_seed(unsigned int seed)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	State& s = S();
-	s.lfsr.reseed(seed << 1);   // vfgs_hw.c:343
-	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
-}
-
-void vfgs_set_scale_shift(int shift)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	if (shift < 2 || shift >= 8) { fail(22, "vfgs_set_scale_shift: %d", shift); die("shift out of 2..7 (vfgs_hw.c:348)"); }
-	if (S().scale_shift != shift + 6 - S().bs) S().tables_dirty = true;   // the LUT image holds pre-shifted scales
-	S().scale_shift = shift + 6 - S().bs;   // vfgs_hw.c:349
-}
-
-void vfgs_set_depth(int depth)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	State& s = S();
-	if (depth != 8 && depth != 10) { fail(23, "vfgs_set_depth: %d", depth); die("depth must be 8 or 10 (vfgs_hw.c:354)"); }
-	if (s.bs != depth - 8) s.tables_dirty = true;
-	s.scale_shift += s.bs - (depth - 8);     // vfgs_hw.c:356-359
-	s.bs = depth - 8;
-}
-
-void vfgs_set_legal_range(int legal)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	State& s = S();
-	s.ymin = s.cmin = legal ? 16 : 0;        // vfgs_hw.c:366-378
-	s.ymax = legal ? 235 : 255;
-	s.cmax = legal ? 240 : 255;
-}
-
-void vfgs_set_chroma_subsampling(int subx, int suby)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	if ((subx != 1 && subx != 2) || (suby != 1 && suby != 2)) { fail(24, "vfgs_set_chroma_subsampling: %d,%d", subx, suby); die("subsampling must be 1 or 2 (vfgs_hw.c:384-385)"); }
-	if (S().csubx == subx && S().csuby == suby) return;
-	S().csubx = subx;
-	S().csuby = suby;
-	S().tables_dirty = true;
-}
-
-void vfgs_add_grain_line(void* Y, void* U, void* V, int y, int width)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	if (line_call(Y, U, V, (unsigned)y, (unsigned)width))
-		die("vfgs_add_grain_line");
-}
-
-void vfgs_add_grain_stripe(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	if (run_host(Y, U, V, y, width, height, stride, cstride))
-		die("vfgs_add_grain_stripe");
-}
-
-void vfgs_hip_line_lookahead(int enable)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().la.enabled = enable != 0;
-	S().la.valid = false;
-}
-
-int vfgs_hip_declare_frame(const void* Y, const void* U, const void* V, unsigned width, unsigned height, unsigned stride, unsigned cstride)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	State& s = S();
-	State::LineAhead& la = s.la;
-	const unsigned sz = s.bs ? 2 : 1, nblk = (width + 15) / 16;
-	if (!Y || !U || !V || height == 0) { la.declared = false; la.frame_h = 0; la.ypitch = la.cpitch = 0; la.valid = false; return 0; }
-	if (stride < nblk * 16 || cstride < nblk * 16 / s.csubx)
-		return fail(6, "vfgs_hip_declare_frame: stride %u/%u too small: whole 16-sample blocks are written (need >= %u/%u)", stride, cstride, nblk * 16, nblk * 16 / s.csubx);
-	la.declared = true;
-	la.bY = (const uint8_t*)Y; la.bU = (const uint8_t*)U; la.bV = (const uint8_t*)V;
-	la.pwidth = width;
-	la.frame_h = height;
-	la.ypitch = (ptrdiff_t)stride * sz; la.cpitch = (ptrdiff_t)cstride * sz;
-	la.have_prev = false;
-	la.valid = false;
-	return 0;
-}
-
-void vfgs_hip_reset_state(void)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	S().gen++;
-	State& s = S();
-	memset(s.bank, 0, sizeof s.bank);
-	memset(s.slut, 0, sizeof s.slut);
-	memset(s.plut, 0, sizeof s.plut);
-	s.dev_origin[0] = s.dev_origin[1] = 0;
-	s.fw_pending.clear();
-	s.fw_last_valid = false;
-	s.scale_shift = 5 + 6;
-	s.bs = 0;
-	s.ymin = s.cmin = 0;
-	s.ymax = s.cmax = 255;
-	s.csubx = s.csuby = 2;
-	s.lfsr.reseed(0xdeadbeefu);
-	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
-	s.tables_dirty = true;
-}
-
-int vfgs_hip_init(int device)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	return ensure_init(device);
-}
-
-void vfgs_hip_shutdown(void)
-{
-	std::lock_guard<std::mutex> g(g_mu);
-	State& s = S();
 	if (!s.inited) return;
 	(void)fw_flush(s, s.own_stream);
 	(void)hipDeviceSynchronize();
@@ -1427,6 +1420,236 @@ void vfgs_hip_shutdown(void)
 	s.own_stream = nullptr; s.ev0 = s.ev1 = nullptr;
 	s.tables_dirty = true;
 	s.inited = false;
+}
+void release_state(State& s) { release_state_impl(s); }
+}  // namespace
+
+// ========================================================================================
+// C ABI
+
+extern "C" {
+
+void vfgs_set_luma_pattern(int index, signed char* P)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_luma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:316)"); }
+	State& s = S();
+	const bool host_slot = !(s.dev_origin[0] >> index & 1);
+	if (host_slot && !memcmp(s.bank[0][index], P, 64 * 64)) return;   // unchanged: the device image stays valid
+	memcpy(s.bank[0][index], P, 64 * 64);   // vfgs_hw.c:317
+	s.dev_origin[0] &= ~(1u << index);
+	s.tables_dirty = true;
+}
+
+void vfgs_set_chroma_pattern(int index, signed char* P)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	State& s = S();
+	if (index < 0 || index >= vfgs::kSlots) { fail(20, "vfgs_set_chroma_pattern: index %d", index); die("bad pattern index (vfgs_hw.c:322)"); }
+	bool same = !(s.dev_origin[1] >> index & 1);
+	for (int i = 0; i < 64 / s.csuby && same; i++)
+		same = !memcmp(s.bank[1][index][i], P + (64 / s.csuby) * i, 64 / s.csubx);
+	if (same) return;                        // unchanged: the device image stays valid
+	for (int i = 0; i < 64 / s.csuby; i++)   // vfgs_hw.c:323-324: pitch from csuby, length from csubx
+		memcpy(s.bank[1][index][i], P + (64 / s.csuby) * i, 64 / s.csubx);
+	s.dev_origin[1] &= ~(1u << index);
+	s.tables_dirty = true;
+}
+
+void vfgs_set_scale_lut(int c, unsigned char lut[])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	if (c < 0 || c > 2) { fail(21, "vfgs_set_scale_lut: component %d", c); die("bad component (vfgs_hw.c:329)"); }
+	if (!memcmp(S().slut[c], lut, 256)) return;   // unchanged (e.g. the same model re-sent with a new seed): nothing to upload
+	memcpy(S().slut[c], lut, 256);
+	S().tables_dirty = true;
+}
+
+void vfgs_set_pattern_lut(int c, unsigned char lut[])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	if (c < 0 || c > 2) { fail(21, "vfgs_set_pattern_lut: component %d", c); die("bad component (vfgs_hw.c:335)"); }
+	if (!memcmp(S().plut[c], lut, 256)) return;
+	memcpy(S().plut[c], lut, 256);
+	S().tables_dirty = true;
+}
+
+void vfgs_set_seed(unsigned int seed)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	State& s = S();
+	s.lfsr.reseed(seed << 1);   // vfgs_hw.c:343
+	s.seed_epoch++;
+	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
+}
+
+void vfgs_set_scale_shift(int shift)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	if (shift < 2 || shift >= 8) { fail(22, "vfgs_set_scale_shift: %d", shift); die("shift out of 2..7 (vfgs_hw.c:348)"); }
+	if (S().scale_shift != shift + 6 - S().bs) S().tables_dirty = true;   // the LUT image holds pre-shifted scales
+	S().scale_shift = shift + 6 - S().bs;   // vfgs_hw.c:349
+}
+
+void vfgs_set_depth(int depth)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	State& s = S();
+	if (depth != 8 && depth != 10) { fail(23, "vfgs_set_depth: %d", depth); die("depth must be 8 or 10 (vfgs_hw.c:354)"); }
+	if (s.bs != depth - 8) s.tables_dirty = true;
+	s.scale_shift += s.bs - (depth - 8);     // vfgs_hw.c:356-359
+	s.bs = depth - 8;
+}
+
+void vfgs_set_legal_range(int legal)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	State& s = S();
+	s.ymin = s.cmin = legal ? 16 : 0;        // vfgs_hw.c:366-378
+	s.ymax = legal ? 235 : 255;
+	s.cmax = legal ? 240 : 255;
+}
+
+void vfgs_set_chroma_subsampling(int subx, int suby)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	if ((subx != 1 && subx != 2) || (suby != 1 && suby != 2)) { fail(24, "vfgs_set_chroma_subsampling: %d,%d", subx, suby); die("subsampling must be 1 or 2 (vfgs_hw.c:384-385)"); }
+	if (S().csubx == subx && S().csuby == suby) return;
+	S().csubx = subx;
+	S().csuby = suby;
+	S().tables_dirty = true;
+}
+
+void vfgs_add_grain_line(void* Y, void* U, void* V, int y, int width)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (line_call(Y, U, V, (unsigned)y, (unsigned)width))
+		die("vfgs_add_grain_line");
+}
+
+void vfgs_add_grain_stripe(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned height, unsigned stride, unsigned cstride)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	if (run_host_multi(Y, U, V, y, width, height, stride, cstride))
+		die("vfgs_add_grain_stripe");
+}
+
+void vfgs_hip_line_lookahead(int enable)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().la.enabled = enable != 0;
+	S().la.valid = false;
+}
+
+int vfgs_hip_declare_frame(const void* Y, const void* U, const void* V, unsigned width, unsigned height, unsigned stride, unsigned cstride)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	State& s = S();
+	State::LineAhead& la = s.la;
+	const unsigned sz = s.bs ? 2 : 1, nblk = (width + 15) / 16;
+	if (!Y || !U || !V || height == 0) { la.declared = false; la.frame_h = 0; la.ypitch = la.cpitch = 0; la.valid = false; return 0; }
+	if (stride < nblk * 16 || cstride < nblk * 16 / s.csubx)
+		return fail(6, "vfgs_hip_declare_frame: stride %u/%u too small: whole 16-sample blocks are written (need >= %u/%u)", stride, cstride, nblk * 16, nblk * 16 / s.csubx);
+	la.declared = true;
+	la.bY = (const uint8_t*)Y; la.bU = (const uint8_t*)U; la.bV = (const uint8_t*)V;
+	la.pwidth = width;
+	la.frame_h = height;
+	la.ypitch = (ptrdiff_t)stride * sz; la.cpitch = (ptrdiff_t)cstride * sz;
+	la.have_prev = false;
+	la.valid = false;
+	return 0;
+}
+
+void vfgs_hip_reset_state(void)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	S().prog_gen++;
+	State& s = S();
+	memset(s.bank, 0, sizeof s.bank);
+	memset(s.slut, 0, sizeof s.slut);
+	memset(s.plut, 0, sizeof s.plut);
+	s.dev_origin[0] = s.dev_origin[1] = 0;
+	s.fw_pending.clear();
+	s.fw_last_valid = false;
+	s.scale_shift = 5 + 6;
+	s.bs = 0;
+	s.ymin = s.cmin = 0;
+	s.ymax = s.cmax = 255;
+	s.csubx = s.csuby = 2;
+	s.lfsr.reseed(0xdeadbeefu);
+	s.seed_epoch++;
+	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
+	s.tables_dirty = true;
+}
+
+int vfgs_hip_init(int device)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	return ensure_init(device);
+}
+
+int vfgs_hip_init_devices(const int* devices, int n)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (!devices || n < 1 || n > kMaxDevices) return fail(26, "vfgs_hip_init_devices: %d devices (1..%d)", n, kMaxDevices);
+	int have = 0;
+	HIP_TRY(hipGetDeviceCount(&have));
+	for (int i = 0; i < n; i++)
+		if (devices[i] < 0 || devices[i] >= have) return fail(2, "vfgs_hip_init_devices: device %d (%d visible)", devices[i], have);
+	for (int i = 1; i < kMaxDevices; i++)
+		if (g_states[i].inited && (i >= n || g_states[i].device != devices[i]))
+		{
+			g_cur = &g_states[i];
+			(void)hipSetDevice(g_states[i].device);
+			release_state(g_states[i]);
+			g_cur = nullptr;
+		}
+	if (int e = ensure_init(devices[0])) return e;
+	for (int i = 1; i < n; i++)
+	{
+		g_cur = &g_states[i];
+		const int e = ensure_init(devices[i]);
+		g_cur = nullptr;
+		if (e) return e;
+		g_states[i].synced_prog = g_states[i].synced_seed = ~0ull;
+		g_states[i].la.enabled = false;
+	}
+	g_ndev = n;
+	(void)hipSetDevice(devices[0]);
+	return 0;
+}
+
+void vfgs_hip_shutdown(void)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	for (int i = kMaxDevices - 1; i >= 0; i--)
+	{
+		if (!g_states[i].inited) continue;
+		g_cur = &g_states[i];
+		(void)hipSetDevice(g_states[i].device);
+		release_state(g_states[i]);
+		g_cur = nullptr;
+	}
+	g_ndev = 1;
 }
 
 int vfgs_hip_add_grain_stripe_dev(void* dY, void* dU, void* dV, unsigned y, unsigned width, unsigned height,
@@ -1486,7 +1709,7 @@ int vfgs_hip_add_grain_frames_host(void* const* Y, void* const* U, void* const* 
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	S().la.valid = false;
-	return run_host_frames(Y, U, V, nframes, width, height, stride, cstride);
+	return run_host_frames_multi(Y, U, V, nframes, width, height, stride, cstride);
 }
 
 void* vfgs_hip_host_alloc(uint64_t bytes)
