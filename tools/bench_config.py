@@ -81,8 +81,10 @@ def main():
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    th0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    host_us = (time.perf_counter() - th0) / args.steps * 1e6     # what the calling thread spends per call (it never waits here)
     e1.record()
     torch.cuda.synchronize()
     launch_us = e0.elapsed_time(e1) / args.steps * 1e3
@@ -90,7 +92,7 @@ def main():
     samples = w * hh * (1 + 2 / (sx * sy))
     nbytes = 2 * sz * samples
     print(json.dumps({"config": args.config, "workload": name, "content": args.content, "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
-                      "launch_us": round(launch_us, 2), "us_per_frame": round(us, 3), "algorithmic_bytes_per_frame": int(nbytes),
+                      "launch_us": round(launch_us, 2), "host_us_per_call": round(host_us, 2), "us_per_frame": round(us, 3), "algorithmic_bytes_per_frame": int(nbytes),
                       "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 4),
                       "Mpixels_per_s": round(w * hh / us, 1), "Msamples_per_s": round(samples / us, 1)}), flush=True)
 

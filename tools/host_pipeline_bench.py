@@ -21,8 +21,12 @@ def main():
     ap.add_argument("--width", type=int, default=7680)
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--trace", default="fgs_sei_10_420")
+    ap.add_argument("--devices", default="0", help="comma separated device list for vfgs_hip_init_devices (a device may repeat)")
     args = ap.parse_args()
     h = hw.VfgsHip(device=0)
+    devs = [int(x) for x in args.devices.split(",")]
+    if len(devs) > 1:
+        h.init_devices(devs)
     rec = T.load_trace(args.trace)
     T.replay(h, rec)
     depth, sx, sy = T.trace_geometry(rec)
@@ -66,7 +70,7 @@ def main():
                 best = min(best, time.perf_counter() - t0)
             res[mode] = best
         for mode, t in res.items():
-            print(json.dumps({"memory": "pinned" if pinned else "pageable", "mode": mode, "frames": n, "geometry": f"{w}x{hh} {depth}-bit {sx}{sy}",
+            print(json.dumps({"devices": devs, "memory": "pinned" if pinned else "pageable", "mode": mode, "frames": n, "geometry": f"{w}x{hh} {depth}-bit {sx}{sy}",
                               "ms_per_frame": round(t / n * 1e3, 3), "GBps_each_way": round(frame_bytes / (t / n) / 1e9, 1),
                               "Mpixels_per_s": round(w * hh / (t / n) / 1e6, 1)}), flush=True)
         del frames

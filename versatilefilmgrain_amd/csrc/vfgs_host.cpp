@@ -45,6 +45,9 @@ extern "C" const unsigned char vfgs_fw_blob[], vfgs_fw_blob_end[];
 #ifndef VFGS_MIN_FILL_PCT
 #define VFGS_MIN_FILL_PCT 25   // a launch should fill at least this share of the chip's wave slots (else: fewer rows per wave)
 #endif
+#ifndef VFGS_RW_WG_BYTES
+#define VFGS_RW_WG_BYTES 24576 // row walk: a workgroup's rows should hold at least this many bytes (where its block row allows)
+#endif
 
 namespace {
 
@@ -856,7 +859,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 				const int units = (int)(d.rowbytes / 16);
 				d.rw_segs = (units + 1 + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
 				int rpw = 1;
-				while (vfgs::kWavesPerWG * rpw * 2 <= (int)rpb && (size_t)vfgs::kWavesPerWG * rpw * d.rowbytes < 49152) rpw *= 2;
+				while (vfgs::kWavesPerWG * rpw * 2 <= (int)rpb && (size_t)vfgs::kWavesPerWG * rpw * d.rowbytes < VFGS_RW_WG_BYTES) rpw *= 2;
 				for (int i = 0; i < rw_shrink && rpw > 1; i++) rpw /= 2;
 				d.rw_rpw = rpw;
 				d.rw_splits = std::max<int>(1, (int)rpb / (vfgs::kWavesPerWG * rpw));
