@@ -1,28 +1,28 @@
 #!/bin/bash
 # Developer helper for gpurun: per-config kernel statistics (rocprofv3 --kernel-trace --stats, program directly after --),
-# the config matrix, the host round-trip experiment.  Everything lands in gpurun_out/r02_*; copy what is to be judged to profiles/.
+# the config matrix, the host round-trip experiment.  Everything lands in gpurun_out/r03_*; copy what is to be judged to profiles/.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out tools/bin
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT/gpurun_out
 rm -rf $R/cfgprof_*
-: > $R/r02_config_lines.jsonl
-for c in 0 1 2 3 4; do
+: > $R/r03_config_lines.jsonl
+for c in 0 1 2 3 4 5 6; do
   for b in 1 8; do
-    python3 tools/bench_config.py --config $c --batch $b >> $R/r02_config_lines.jsonl 2>> $R/r02_config.err
+    python3 tools/bench_config.py --config $c --batch $b >> $R/r03_config_lines.jsonl 2>> $R/r03_config.err
   done
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/cfgprof_$c -- python3 $GRAFT_REPO_ROOT/tools/bench_config.py --config $c --batch 8 > $R/cfgprof_$c.log 2>&1 )
 done
-cat $R/r02_config_lines.jsonl
+cat $R/r03_config_lines.jsonl
 python3 - <<'PY'
 import csv, glob, json
 rows = []
-for c in range(5):
+for c in range(7):
     for f in glob.glob(f'gpurun_out/cfgprof_{c}/**/*kernel_stats.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'grain_kernel' in r['Name']:
+            if 'grain_' in r['Name'] and 'kernel' in r['Name']:
                 rows.append({'config': c, **{k: r[k] for k in ('Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'MinNs', 'MaxNs', 'StdDev')}})
-json.dump(rows, open('gpurun_out/r02_config_kernel_stats.json', 'w'), indent=1)
+json.dump(rows, open('gpurun_out/r03_config_kernel_stats.json', 'w'), indent=1)
 print(json.dumps(rows, indent=1))
 PY
-hipcc -O2 --offload-arch=gfx950 tools/h2d_pipeline.hip -o tools/bin/h2d_pipeline 2> /dev/null && timeout -k 5 200 ./tools/bin/h2d_pipeline > $R/r02_h2d_pipeline.log 2>&1; cat $R/r02_h2d_pipeline.log
+python3 tools/host_pipeline_bench.py > $R/r03_host_pipeline.jsonl 2>/dev/null; python3 tools/host_pipeline_bench.py --devices 0,0 >> $R/r03_host_pipeline.jsonl 2>/dev/null; cat $R/r03_host_pipeline.jsonl
