@@ -1,0 +1,150 @@
+"""GPU (MI355X): edge cases of the row-walk kernels (vfgs_kernel.hip 4.1) against the oracle, through the C ABI.
+
+A wave streams whole rows in groups of four 1 KiB positions; the geometry that can go wrong is exactly where a row ends
+relative to positions and groups (the position behind the last unit, rows that end on a position or group boundary, one-unit
+tails), how many rows a wave walks (one, two or four, by picture size), stripes that begin or end inside a block row, frames
+whose last block row is partial, batches, out-of-place copies, and the widest row the parameter table holds (512 blocks;
+one block more falls back to the tiled kernels).  Garbage in the stride padding must survive."""
+import numpy as np
+import pytest
+
+import vfgs_testlib as T
+from gpu_util import DevFrame, stream_ptr
+
+pytestmark = pytest.mark.gpu
+
+FORMATS = ["fgs_sei_10_420", "fgs_afgs1_test1_8_420", "fgs_sei_8_420", "fgs_afgs1_test1_8_444", "fgs_sei_10_422", "fgs_sei_ff_test6_8_422", "fgs_sei_10_444",
+           "fgs_sei_ff_test6_10_440"]
+# 10-bit luma: a unit = 8 samples, a position = 512 samples, a group = 2048; 8-bit: twice that
+WIDTHS = [136, 504, 512, 520, 1016, 1024, 1032, 2040, 2048, 2056, 2064, 4096, 4104]
+HEIGHTS = [16, 17, 33, 64, 70]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from versatilefilmgrain_amd import hw
+    return hw.VfgsHip(device=0)
+
+
+def program(hip, name):
+    hip.lib.vfgs_hip_reset_state()
+    rec = T.load_trace(name)
+    T.replay(hip, rec)
+    ora = T.OracleHW()
+    T.replay(ora, rec)
+    return ora, T.trace_geometry(rec)
+
+
+def garbage_frame(width, height, depth, sx, sy, seed, stride=None, cstride=None):
+    rng = np.random.default_rng(seed)
+    f = T.Frame(width, height, depth, sx, sy, stride=stride, cstride=cstride)
+    for p in f.planes():
+        p[...] = rng.integers(0, 1 << (16 if depth > 8 else 8), p.shape).astype(f.dtype)
+    return f
+
+
+def device_pitches(f):
+    """16-byte aligned rows: what the device entry points need (the reference's own strides are multiples of 64 samples)."""
+    return f.stride, f.cstride
+
+
+@pytest.mark.parametrize("name", FORMATS)
+@pytest.mark.parametrize("width", WIDTHS)
+def test_row_ends_on_and_around_position_and_group_boundaries(hip, name, width):
+    ora, (depth, sx, sy) = program(hip, name)
+    if depth == 8 and sx == 2 and ((width + 15) // 16) % 2:
+        pytest.skip("odd block count at 8-bit 4:2:x: rows are not whole units, tiled kernels (covered elsewhere)")
+    for i, height in enumerate(HEIGHTS):
+        f = garbage_frame(width, height, depth, sx, sy, width * 7 + i)
+        want = f.copy()
+        ora.add_grain_frame(want)
+        d = DevFrame(f)
+        hip.add_grain_frame_dev(*d.ptrs(), f.width, f.height, f.stride, f.cstride, stream_ptr())
+        got = d.download()
+        assert got.equal_all(want), (name, width, height)
+        assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name,width,height", [("fgs_sei_10_420", 1920, 1080), ("fgs_afgs1_test1_8_420", 1920, 1080), ("fgs_sei_10_444", 720, 404),
+                                               ("fgs_sei_10_422", 1280, 360), ("fgs_sei_10_420", 3840, 100)])
+def test_stripes_that_cut_block_rows_at_every_rows_per_wave(hip, name, width, height):
+    """Frames as sequences of device stripes whose edges fall anywhere inside block rows; small pictures walk two or four rows
+    per wave, so first / last rows of a wave's walk get cut."""
+    ora, (depth, sx, sy) = program(hip, name)
+    f = garbage_frame(width, height, depth, sx, sy, height)
+    want = f.copy()
+    ora.add_grain_frame(want)
+    d = DevFrame(f)
+    cuts = [0, 2 * sy, 16, 16 + 6 * sy, 48, 50, 51 if sy == 1 else 52, height // 2 // sy * sy, height]
+    cuts = sorted(set(c for c in cuts if 0 <= c <= height))
+    for y0, y1 in zip(cuts, cuts[1:]):
+        hip.add_grain_stripe_dev(*d.ptrs(y0), y0, f.width, y1 - y0, f.stride, f.cstride, stream_ptr())
+    got = d.download()
+    assert got.equal_all(want)
+    assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("width,expect_rowwalk", [(8192, True), (8176, True), (8208, False)])
+def test_widest_row_of_the_parameter_table_and_one_block_more(hip, width, expect_rowwalk):
+    """512 blocks per row is the last width the row walk takes; 513 blocks run on the tiled kernels.  Same results either way."""
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    f = garbage_frame(width, 48, depth, sx, sy, width)
+    want = f.copy()
+    ora.add_grain_frame(want)
+    d = DevFrame(f)
+    hip.add_grain_frame_dev(*d.ptrs(), f.width, f.height, f.stride, f.cstride, stream_ptr())
+    assert d.download().equal_all(want)
+    assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_444"])
+def test_batches_with_frame_pitch_and_out_of_place(hip, name):
+    """5 frames in one launch (frame pitch larger than a frame), in place and as a copy into a second set of buffers."""
+    import torch
+    ora, (depth, sx, sy) = program(hip, name)
+    W, H, N = 1032, 90, 5
+    frames = [garbage_frame(W, H, depth, sx, sy, 100 + i) for i in range(N)]
+    want = [f.copy() for f in frames]
+    for w in want:
+        ora.add_grain_frame(w)
+    sz = frames[0].Y.itemsize
+    f0 = frames[0]
+    ypitch = (f0.Y.size * sz + 256 + 15) // 16 * 16
+    cpitch = (f0.U.size * sz + 512 + 15) // 16 * 16
+
+    def upload():
+        Y = torch.zeros(N * ypitch, dtype=torch.uint8, device="cuda"); U = torch.zeros(N * cpitch, dtype=torch.uint8, device="cuda"); V = torch.zeros(N * cpitch, dtype=torch.uint8, device="cuda")
+        for i, f in enumerate(frames):
+            Y[i * ypitch:i * ypitch + f.Y.size * sz] = torch.from_numpy(f.Y.view(np.uint8).ravel().copy()).cuda()
+            U[i * cpitch:i * cpitch + f.U.size * sz] = torch.from_numpy(f.U.view(np.uint8).ravel().copy()).cuda()
+            V[i * cpitch:i * cpitch + f.V.size * sz] = torch.from_numpy(f.V.view(np.uint8).ravel().copy()).cuda()
+        return Y, U, V
+
+    def check(Y, U, V, cols=None):
+        """cols: compare only the first cols luma columns (an out-of-place destination's stride padding is never written)"""
+        torch.cuda.synchronize()
+        cy = cols or f0.stride
+        cc = (cols // sx) if cols else f0.cstride
+        for i, w in enumerate(want):
+            gy = Y[i * ypitch:i * ypitch + w.Y.size * sz].cpu().numpy().view(w.dtype).reshape(w.Y.shape)
+            gu = U[i * cpitch:i * cpitch + w.U.size * sz].cpu().numpy().view(w.dtype).reshape(w.U.shape)
+            gv = V[i * cpitch:i * cpitch + w.V.size * sz].cpu().numpy().view(w.dtype).reshape(w.V.shape)
+            # rows the picture has (the allocation's padding rows below it are never touched by either side)
+            assert np.array_equal(gy[:H, :cy], w.Y[:H, :cy]) and np.array_equal(gu[:H // sy, :cc], w.U[:H // sy, :cc]) and np.array_equal(gv[:H // sy, :cc], w.V[:H // sy, :cc]), i
+
+    Y, U, V = upload()
+    hip.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), W, H, f0.stride, f0.cstride, N, ypitch, cpitch, stream_ptr())
+    check(Y, U, V)
+    st = hip.seed_state()
+    assert st == ora.seed_state()
+    # the same batch again, out of place, from a fresh copy of the inputs and the same seed state as before
+    ora2, _ = program(hip, name)
+    sY, sU, sV = upload()
+    dY, dU, dV = torch.zeros_like(sY), torch.zeros_like(sU), torch.zeros_like(sV)
+    hip.add_grain_copy_dev(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), dY.data_ptr(), dU.data_ptr(), dV.data_ptr(), W, H, 0, H,
+                           f0.stride, f0.cstride, N, ypitch, cpitch, stream_ptr())
+    check(dY, dU, dV, cols=(W + 15) // 16 * 16)
+    assert not dY.view(torch.int16 if depth > 8 else torch.uint8).reshape(N, -1)[:, :f0.Y.size].reshape(N, -1, f0.stride)[:, :H, (W + 15) // 16 * 16:].any()   # ... and stays untouched
+    assert hip.seed_state() == st

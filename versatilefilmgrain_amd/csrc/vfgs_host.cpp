@@ -429,6 +429,11 @@ struct State {
 	hipEvent_t bank_ev = nullptr;             // ... and their completion, for the (rare) change of stream
 	bool bank_used = false;
 
+	// what every processing call needs to know about the pattern LUTs (768 entries), worked out when they change, not per call
+	bool plut_seen = false;           // the three fields below are valid
+	int plut_bad_c = -1, plut_bad_i = 0;      // an entry that selects a slot > 8 (undefined in the reference), or -1
+	int plut_slot[3] = {0, 0, 0};     // per component: the slot every intensity selects, or -1
+
 	// ---- several devices in one process (vfgs_hip_init_devices): states 1.. are replicas of state 0 --------------
 	uint64_t prog_gen = 0;            // bumped whenever the programmed state (banks, LUTs, parameters, patterns) may have changed
 	uint64_t seed_epoch = 0;          // bumped whenever the LFSR is reloaded
@@ -683,12 +688,25 @@ void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool
 	}
 }
 
-int check_luts(const State& s)
+void digest_pluts(State& s)
 {
+	if (s.plut_seen) return;
+	s.plut_bad_c = -1;
 	for (int c = 0; c < 3; c++)
-		for (int i = 0; i < 256; i++)
-			if ((s.plut[c][i] >> 4) > vfgs::kSlots)
-				return fail(4, "pattern LUT %d[%d] selects slot %d > 8 (undefined in the reference, vfgs_hw.c:49,212)", c, i, s.plut[c][i] >> 4);
+	{
+		s.plut_slot[c] = uniform_slot(s.plut[c]);
+		for (int i = 0; i < 256 && s.plut_bad_c < 0; i++)
+			if ((s.plut[c][i] >> 4) > vfgs::kSlots) { s.plut_bad_c = c; s.plut_bad_i = i; }
+	}
+	s.plut_seen = true;
+}
+
+int check_luts(State& s)
+{
+	digest_pluts(s);
+	if (s.plut_bad_c >= 0)
+		return fail(4, "pattern LUT %d[%d] selects slot %d > 8 (undefined in the reference, vfgs_hw.c:49,212)", s.plut_bad_c, s.plut_bad_i,
+		            s.plut[s.plut_bad_c][s.plut_bad_i] >> 4);
 	return 0;
 }
 
@@ -696,7 +714,7 @@ int check_luts(const State& s)
 int upload_tables(State& s, hipStream_t stream, bool want_general)
 {
 	if (int e = check_luts(s)) return e;
-	const int slot[3] = {uniform_slot(s.plut[0]), uniform_slot(s.plut[1]), uniform_slot(s.plut[2])};
+	const int slot[3] = {s.plut_slot[0], s.plut_slot[1], s.plut_slot[2]};     // (check_luts has just digested them)
 #ifdef VFGS_NO_ONE_PATTERN      // tools/gpu_variants.sh: always the general form
 	want_general = true;
 #endif
@@ -1269,6 +1287,7 @@ int sync_replica(State& r, State& p)
 		               r.cmax != p.cmax || r.csubx != p.csubx || r.csuby != p.csuby || r.dev_origin[0] != p.dev_origin[0] ||
 		               r.dev_origin[1] != p.dev_origin[1];
 		memcpy(r.bank, p.bank, sizeof r.bank); memcpy(r.slut, p.slut, sizeof r.slut); memcpy(r.plut, p.plut, sizeof r.plut);
+		r.plut_seen = false;
 		r.scale_shift = p.scale_shift; r.bs = p.bs; r.ymin = p.ymin; r.ymax = p.ymax; r.cmin = p.cmin; r.cmax = p.cmax;
 		r.csubx = p.csubx; r.csuby = p.csuby;
 		r.dev_origin[0] = p.dev_origin[0]; r.dev_origin[1] = p.dev_origin[1];
@@ -1482,6 +1501,7 @@ void vfgs_set_pattern_lut(int c, unsigned char lut[])
 	if (c < 0 || c > 2) { fail(21, "vfgs_set_pattern_lut: component %d", c); die("bad component (vfgs_hw.c:335)"); }
 	if (!memcmp(S().plut[c], lut, 256)) return;
 	memcpy(S().plut[c], lut, 256);
+	S().plut_seen = false;
 	S().tables_dirty = true;
 }
 
@@ -1590,6 +1610,7 @@ void vfgs_hip_reset_state(void)
 	memset(s.bank, 0, sizeof s.bank);
 	memset(s.slut, 0, sizeof s.slut);
 	memset(s.plut, 0, sizeof s.plut);
+	s.plut_seen = false;
 	s.dev_origin[0] = s.dev_origin[1] = 0;
 	s.fw_pending.clear();
 	s.fw_last_valid = false;
