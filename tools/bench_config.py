@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--content", choices=["uniform", "ramp"], default="uniform",
                     help="uniform: random over the full code range (worst case for LUT / pattern divergence, SURVEY 8d); "
                          "ramp: smooth diagonal ramp + -4..+4 noise (natural-like, reported separately)")
+    ap.add_argument("--mode", choices=["inplace", "copy", "copy8"], default="inplace",
+                    help="inplace (default); copy: out of place, same depth; copy8: 10-bit in, 8-bit out (the CLI's --outdepth 8 fused into the store)")
     ap.add_argument("--width", type=int, default=0, help="override the picture width (experiments)")
     ap.add_argument("--height", type=int, default=0, help="override the picture height (experiments)")
     args = ap.parse_args()
@@ -70,9 +72,24 @@ def main():
     sets = [(mk(hh, w), mk(hh // sy, w // sx), mk(hh // sy, w // sx)) for _ in range(pool)]
     st = torch.cuda.current_stream().cuda_stream
 
+    dsts = None
+    if args.mode != "inplace":
+        ddt = torch.uint8 if args.mode == "copy8" else dt
+        dsts = [(torch.zeros((args.batch, hh, w), dtype=ddt, device="cuda"), torch.zeros((args.batch, hh // sy, w // sx), dtype=ddt, device="cuda"),
+                 torch.zeros((args.batch, hh // sy, w // sx), dtype=ddt, device="cuda")) for _ in range(min(pool, 4))]
+
     def step(i):
         Y, U, V = sets[i % pool]
-        h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, w, w // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, st)
+        if args.mode == "inplace":
+            h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, w, w // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, st)
+            return
+        dY, dU, dV = dsts[i % len(dsts)]
+        if args.mode == "copy":
+            h.add_grain_copy_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), dY.data_ptr(), dU.data_ptr(), dV.data_ptr(), w, hh, 0, hh, w, w // sx,
+                                 args.batch, Y[0].numel() * sz, U[0].numel() * sz, st)
+        else:
+            h.add_grain_copy8_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), dY.data_ptr(), dU.data_ptr(), dV.data_ptr(), w, hh, 0, hh, w, w // sx,
+                                  w, w // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, dY[0].numel(), dU[0].numel(), st)
     t0, n = time.perf_counter(), 0
     while (time.perf_counter() - t0) * 1e3 < args.preroll_ms:
         for _ in range(8):
@@ -90,8 +107,8 @@ def main():
     launch_us = e0.elapsed_time(e1) / args.steps * 1e3
     us = launch_us / args.batch
     samples = w * hh * (1 + 2 / (sx * sy))
-    nbytes = 2 * sz * samples
-    print(json.dumps({"config": args.config, "workload": name, "content": args.content, "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
+    nbytes = (sz + (1 if args.mode == "copy8" else sz)) * samples
+    print(json.dumps({"config": args.config, "workload": name, "content": args.content, "mode": args.mode, "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
                       "launch_us": round(launch_us, 2), "host_us_per_call": round(host_us, 2), "us_per_frame": round(us, 3), "algorithmic_bytes_per_frame": int(nbytes),
                       "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 4),
                       "Mpixels_per_s": round(w * hh / us, 1), "Msamples_per_s": round(samples / us, 1)}), flush=True)

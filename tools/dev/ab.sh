@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 for round in $(seq 1 ${ROUNDS:-3}); do
 for n in "$@"; do
-  for cb in ${VCFG:-4:8}; do c=${cb%:*}; b=${cb#*:}; VFGS_ALLOW_DEV_BUILD=1 VFGS_LIB=$GRAFT_REPO_ROOT/tools/bin/$n.so python3 tools/bench_config.py --config $c --batch $b --steps ${STEPS:-100} 2>/dev/null | python3 -c "
+  for cb in ${VCFG:-4:8}; do c=${cb%:*}; b=${cb#*:}; VFGS_ALLOW_DEV_BUILD=1 VFGS_LIB=$GRAFT_REPO_ROOT/tools/bin/$n.so python3 tools/bench_config.py --config $c --batch $b --steps ${STEPS:-100} ${EXTRA:-} 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); print('round $round  %-28s cfg %d x%d  %8.3f us/frame  %.4f' % ('$n', d['config'], d['frames_per_launch'], d['us_per_frame'], d['frac_of_8TBps']))"; done
