@@ -803,9 +803,10 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 //     the overlap lines, those of the block row above) are computed ONCE per workgroup, one or two blocks per thread, and
 //     kept in LDS behind the table image; a lane reads its 1-3 entries per segment (the tiled kernels hold 4 segments x
 //     1-3 runs x 2 in registers: the 8-bit 4:2:x kernels spilled on that);
-//   * lanes compute the half-block shifted bytes as in the aligned kernels (DPP rotation by one lane, the carry between
-//     consecutive segments of a row travels in SGPRs); a segment's units are stored one step later, once lane 0 of the next
-//     segment has delivered the last dwords of its lane 63;
+//   * lanes compute the half-block shifted bytes as in the aligned kernels: rotation by one lane with DPP wave_shr / wave_shl,
+//     the hand-over between consecutive segments of a row with wave_ror / wave_rol (the previous segment's lane 63 waits in
+//     lane 0 of a register and enters as the `old` operand of the shift: no v_readlane, no scalar round trip); a segment's
+//     units are stored one step later, once lane 0 of the next segment has delivered the last dwords of its lane 63;
 //   * row bases and segment offsets live in the buffer descriptor (base, num_records = bytes of the row left), so the
 //     hardware range check covers every access of every lane: lanes behind the row's end load 0 and store nothing.
 template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE>
