@@ -164,6 +164,17 @@ const char* vfgs_hip_last_error_string(void);
 int vfgs_hip_timer_begin(void* stream);
 int vfgs_hip_timer_end(void* stream, float* elapsed_ms);
 
+/* Overlap region for device-resident frames that arrive ONE PER CALL (the reference's call pattern, vfgs_main.c:771-790, with the
+ * frames already in HBM): a kernel launch pays its fill and drain -- a 4320p frame runs at 0.60 of the HBM peak alone and at 0.72
+ * when the next frame's launch overlaps its tail.  Between _begin(stream) and _end(stream) the caller promises that the
+ * device-pointer calls it makes on `stream` are independent of each other (distinct frames) and of anything else queued on
+ * `stream` after _begin; the library runs them alternately on two internal streams forked from `stream` at _begin and joined
+ * back into it at _end (events only there, nothing between the launches).  Work queued on `stream` before _begin is complete
+ * before the first call starts; work queued after _end sees every result.  Results and seed registers are those of the same
+ * calls without the region.  One region at a time.  0 or an error code. */
+int vfgs_hip_overlap_begin(void* stream);
+int vfgs_hip_overlap_end(void* stream);
+
 /* Several devices in ONE process, for frames that live in host memory (SURVEY 8e x 8f row f3; the reference's frame loop and
  * file I/O, vfgs_main.c:664-682 / yuv.c:162-214, are one process and one thread).  After this call vfgs_add_grain_stripe and
  * vfgs_hip_add_grain_frames_host give every listed device a stripe of whole 16-line block rows of each frame and run the

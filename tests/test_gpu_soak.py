@@ -14,13 +14,15 @@ pytestmark = pytest.mark.gpu
 CASES = [
     # trace, width, height, launches, entry point
     ("fgs_sei_10_420", 7680, 4320, 2, "part"),          # bench.py's shape: 7680x4320 10-bit 4:2:0, fgs_sei, 8 frames per launch
+    ("fgs_sei_10_420", 7680, 4320, 3, "part_region"),   # the same launches inside an overlap region (two run at a time, one frame front each)
+    ("fgs_sei_10_420", 7680, 4320, 1, "part3"),         # odd frame count: the two frame fronts of one launch, last front half empty
     ("fgs_afgs1_test1_8_444", 3840, 2160, 2, "frames"),  # BASELINE config 4
     ("fgs_afgs1_test1_8_420", 3840, 2160, 2, "frames"),  # the mainstream AFGS1 case (8-bit 4:2:0, vfgs_hw.c:352-362)
     ("fgs_sei_8_420", 3840, 2160, 1, "frames"),          # 8-bit 4:2:0 with per-sample pattern selection
 ]
 
 
-@pytest.mark.parametrize("name,w,hh,launches,entry", CASES, ids=[f"{c[0]}_{c[1]}x{c[2]}" for c in CASES])
+@pytest.mark.parametrize("name,w,hh,launches,entry", CASES, ids=[f"{c[0]}_{c[1]}x{c[2]}_{c[4]}" for c in CASES])
 def test_queued_full_size_batches_equal_oracle(name, w, hh, launches, entry):
     import torch
     from versatilefilmgrain_amd import hw
@@ -35,20 +37,24 @@ def test_queued_full_size_batches_equal_oracle(name, w, hh, launches, entry):
     dt = torch.int16 if depth > 8 else torch.uint8
     npd = np.uint16 if depth > 8 else np.uint8
     sz = 2 if depth > 8 else 1
-    batch = 8
+    batch = 3 if entry == "part3" else 8
     stride, cstride = w, w // sx
     g = torch.Generator(device="cuda").manual_seed(11)
     mk = lambda r, c: torch.randint(0, 1 << depth, (batch, r, c), dtype=torch.int32, device="cuda", generator=g).to(dt)
     sets = [(mk(hh, stride), mk(hh // sy, cstride), mk(hh // sy, cstride)) for _ in range(launches)]
     src = [tuple(t.cpu().numpy().view(npd) for t in s_) for s_ in sets]
     torch.cuda.synchronize()
+    if entry == "part_region":
+        h.overlap_begin(st)
     for Y, U, V in sets:      # all launches queued back to back, nothing in between
-        if entry == "part":
+        if entry in ("part", "part3", "part_region"):
             h.add_grain_frames_part_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, 0, hh, stride, cstride, batch,
                                         Y[0].numel() * sz, U[0].numel() * sz, st)
         else:
             h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, stride, cstride, batch,
                                    Y[0].numel() * sz, U[0].numel() * sz, st)
+    if entry == "part_region":
+        h.overlap_end(st)
     torch.cuda.synchronize()
     bad = []
     for li, ((Y, U, V), (sY, sU, sV)) in enumerate(zip(sets, src)):
@@ -61,3 +67,65 @@ def test_queued_full_size_batches_equal_oracle(name, w, hh, launches, entry):
                 bad.append((li, f))
     assert not bad, f"frames (launch, index) that differ from the oracle: {bad}"
     assert h.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name,w,hh,calls", [("fgs_sei_10_420", 7680, 4320, 5), ("fgs_sei_10_420", 1920, 1080, 9), ("fgs_afgs1_test1_8_420", 3840, 2160, 6)],
+                         ids=["4320p", "1080p", "2160p_8bit"])
+def test_overlap_region_one_frame_per_call_equals_oracle(name, w, hh, calls):
+    """vfgs_hip_overlap_begin/_end: independent frames, one per call (the reference's call pattern, vfgs_main.c:771-790), run
+    alternately on two internal streams.  The frames are produced on the caller's stream right before the region (the fork must
+    order them) and read on it right after (the join must order that); results and seeds as without the region."""
+    import torch
+    from versatilefilmgrain_amd import hw
+
+    h = hw.VfgsHip(device=0)
+    rec = T.load_trace(name)
+    T.replay(h, rec)
+    ora = T.OracleHW()
+    T.replay(ora, rec)
+    depth, sx, sy = T.trace_geometry(rec)
+    dt = torch.int16 if depth > 8 else torch.uint8
+    npd = np.uint16 if depth > 8 else np.uint8
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda r, c: torch.randint(0, 1 << depth, (calls, r, c), dtype=torch.int32, device="cuda", generator=g).to(dt)
+    Y0, U0, V0 = mk(hh, w), mk(hh // sy, w // sx), mk(hh // sy, w // sx)
+    src = tuple(t.cpu().numpy().view(npd) for t in (Y0, U0, V0))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        st = side.cuda_stream
+        Y, U, V = Y0.clone(), U0.clone(), V0.clone()          # producer on the caller's stream: the region must wait for it
+        h.overlap_begin(st)
+        for f in range(calls):
+            h.add_grain_frame_dev(Y[f].data_ptr(), U[f].data_ptr(), V[f].data_ptr(), w, hh, w, w // sx, st)
+        h.overlap_end(st)
+        oY, oU, oV = Y.clone(), U.clone(), V.clone()          # consumer on the caller's stream: must see every frame finished
+    side.synchronize()
+    gY, gU, gV = (t.cpu().numpy().view(npd) for t in (oY, oU, oV))
+    bad = []
+    for f in range(calls):
+        fr = T.Frame(w, hh, depth, sx, sy, stride=w, cstride=w // sx)
+        fr.Y[:hh], fr.U[:hh // sy], fr.V[:hh // sy] = src[0][f], src[1][f], src[2][f]
+        ora.add_grain_frame(fr)
+        if not (np.array_equal(fr.Y[:hh], gY[f]) and np.array_equal(fr.U[:hh // sy], gU[f]) and np.array_equal(fr.V[:hh // sy], gV[f])):
+            bad.append(f)
+    assert not bad, f"frames that differ from the oracle: {bad}"
+    assert h.seed_state() == ora.seed_state()
+
+
+def test_overlap_region_errors():
+    import torch
+    from versatilefilmgrain_amd import hw
+
+    h = hw.VfgsHip(device=0)
+    st = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(hw.VfgsHipError):
+        h.overlap_end(st)                 # nothing open
+    h.overlap_begin(st)
+    with pytest.raises(hw.VfgsHipError):
+        h.overlap_begin(st)               # one region at a time
+    other = torch.cuda.Stream()
+    with pytest.raises(hw.VfgsHipError):
+        h.overlap_end(other.cuda_stream)  # not the region's stream
+    h.overlap_end(st)
+    torch.cuda.synchronize()

@@ -43,6 +43,8 @@ def main():
                          "ramp: smooth diagonal ramp + -4..+4 noise (natural-like, reported separately)")
     ap.add_argument("--mode", choices=["inplace", "copy", "copy8"], default="inplace",
                     help="inplace (default); copy: out of place, same depth; copy8: 10-bit in, 8-bit out (the CLI's --outdepth 8 fused into the store)")
+    ap.add_argument("--overlap", action="store_true", help="time the calls inside one vfgs_hip_overlap_begin/_end region (independent frames, one per call)")
+    ap.add_argument("--streams", type=int, default=1, help="experiment: issue consecutive launches round-robin on this many streams (they may overlap)")
     ap.add_argument("--width", type=int, default=0, help="override the picture width (experiments)")
     ap.add_argument("--height", type=int, default=0, help="override the picture height (experiments)")
     args = ap.parse_args()
@@ -74,6 +76,8 @@ def main():
         return torch.randint(0, 1 << depth, (args.batch, rows, cols), dtype=torch.int32, device="cuda", generator=g).to(dt)
     sets = [(mk(hh, w), mk(hh // sy, w // sx), mk(hh // sy, w // sx)) for _ in range(pool)]
     st = torch.cuda.current_stream().cuda_stream
+    extra_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
+    stream_of = (lambda i: extra_streams[i % len(extra_streams)].cuda_stream) if extra_streams else (lambda i: st)
 
     dsts = None
     if args.mode != "inplace":
@@ -84,7 +88,7 @@ def main():
     def step(i):
         Y, U, V = sets[i % pool]
         if args.mode == "inplace":
-            h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, w, w // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, st)
+            h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, w, w // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, stream_of(i))
             return
         dY, dU, dV = dsts[i % len(dsts)]
         if args.mode == "copy":
@@ -95,23 +99,35 @@ def main():
                                   w, w // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, dY[0].numel(), dU[0].numel(), st)
     t0, n = time.perf_counter(), 0
     while (time.perf_counter() - t0) * 1e3 < args.preroll_ms:
+        if args.overlap:
+            h.overlap_begin(st)       # (the first region creates the two internal streams and their hardware queues: milliseconds, once)
         for _ in range(8):
             step(n)
             n += 1
+        if args.overlap:
+            h.overlap_end(st)
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
     e0.record()
     th0 = time.perf_counter()
+    if args.overlap:
+        h.overlap_begin(st)
     for i in range(args.steps):
         step(i)
+    if args.overlap:
+        h.overlap_end(st)
     host_us = (time.perf_counter() - th0) / args.steps * 1e6     # what the calling thread spends per call (it never waits here)
+    if extra_streams:
+        for xs in extra_streams:
+            torch.cuda.current_stream().wait_stream(xs)
     e1.record()
     torch.cuda.synchronize()
     launch_us = e0.elapsed_time(e1) / args.steps * 1e3
     us = launch_us / args.batch
     samples = w * hh * (1 + 2 / (sx * sy))
     nbytes = (sz + (1 if args.mode == "copy8" else sz)) * samples
-    print(json.dumps({"config": args.config, "workload": name, "content": args.content, "mode": args.mode, "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
+    print(json.dumps({"config": args.config, "workload": name, "content": args.content, "mode": args.mode, "streams": args.streams, "overlap_region": bool(args.overlap), "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
                       "launch_us": round(launch_us, 2), "host_us_per_call": round(host_us, 2), "us_per_frame": round(us, 3), "algorithmic_bytes_per_frame": int(nbytes),
                       "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 4),
                       "Mpixels_per_s": round(w * hh / us, 1), "Msamples_per_s": round(samples / us, 1)}), flush=True)

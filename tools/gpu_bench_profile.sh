@@ -7,11 +7,11 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/bench_driver_args.json 2> gpu
 python bench.py > gpurun_out/bench_default.json 2>> gpurun_out/bench_default.err; cat gpurun_out/bench_default.json
 python bench.py --batch 1 --steps 1000 --warmup 300 --pool 24 --no-cpu > gpurun_out/bench_b1.json 2>> gpurun_out/bench_default.err; cat gpurun_out/bench_b1.json
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity > $GRAFT_REPO_ROOT/gpurun_out/prof_kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_write -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_sq -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_sq.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_lds -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_lds.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --no-region > $GRAFT_REPO_ROOT/gpurun_out/prof_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --no-region --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_write -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --no-region --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_sq -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --no-region --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_sq.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_lds -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --no-region --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_lds.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, collections, json, hashlib, datetime

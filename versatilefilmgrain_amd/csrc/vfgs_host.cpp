@@ -434,6 +434,14 @@ struct State {
 	int plut_bad_c = -1, plut_bad_i = 0;      // an entry that selects a slot > 8 (undefined in the reference), or -1
 	int plut_slot[3] = {0, 0, 0};     // per component: the slot every intensity selects, or -1
 
+	// ---- overlap region (vfgs_hip_overlap_begin / _end): device-pointer calls on `user` run alternately on two internal streams
+	struct Overlap {
+		bool active = false;
+		hipStream_t user = nullptr, s[2] = {nullptr, nullptr};
+		hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+		unsigned n = 0;
+	} ov;
+
 	// ---- several devices in one process (vfgs_hip_init_devices): states 1.. are replicas of state 0 --------------
 	uint64_t prog_gen = 0;            // bumped whenever the programmed state (banks, LUTs, parameters, patterns) may have changed
 	uint64_t seed_epoch = 0;          // bumped whenever the LFSR is reloaded
@@ -950,8 +958,16 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 
 	// one workgroup per (plane, group of rows, group of tiles), numbered in memory order; not persistent
 	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
-	if (per_frame > 0x7fffffffL || nframes > 65535) return fail(14, "launch too large");
+	if (per_frame > 0x3fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;
+	// row walk, batches of large frames: two frames are swept at the same time (vfgs_kernel.hip grain_rw_kernel)
+#ifdef VFGS_NO_FRONTS
+	a.lfronts = 0;
+#else
+	// (not inside an overlap region: there the second sweep is the launch on the other stream, and four fronts lose 15 %)
+	const bool in_region = g_states[0].ov.active && (stream == g_states[0].ov.s[0] || stream == g_states[0].ov.s[1]);
+	a.lfronts = (rowwalk && nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
+#endif
 	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, rowwalk ? 2 : (aligned ? 1 : 0), (int)per_frame, stream));
 	return 0;
 }
@@ -1399,6 +1415,14 @@ int run_host_frames_multi(void* const* Y, void* const* U, void* const* V, unsign
 
 void release_state(State& s);
 
+// inside an overlap region the device-pointer calls made on the region's stream alternate between two internal streams
+hipStream_t pick_stream(void* stream)
+{
+	State& s = g_states[0];
+	if (s.ov.active && (hipStream_t)stream == s.ov.user) return s.ov.s[s.ov.n++ & 1];
+	return (hipStream_t)stream;
+}
+
 }  // namespace
 
 namespace vfgs {
@@ -1436,6 +1460,14 @@ void release_state_impl(State& s)
 	s.bank_used = false; s.bank_stream = nullptr;
 	s.dev_origin[0] = s.dev_origin[1] = 0;
 	s.fw_last_valid = false;
+	for (int i = 0; i < 2; i++)
+	{
+		if (s.ov.s[i]) (void)hipStreamDestroy(s.ov.s[i]);
+		if (s.ov.join[i]) (void)hipEventDestroy(s.ov.join[i]);
+		s.ov.s[i] = nullptr; s.ov.join[i] = nullptr;
+	}
+	if (s.ov.fork) (void)hipEventDestroy(s.ov.fork);
+	s.ov.fork = nullptr; s.ov.active = false;
 	if (s.own_stream) (void)hipStreamDestroy(s.own_stream);
 	if (s.ev0) (void)hipEventDestroy(s.ev0);
 	if (s.ev1) (void)hipEventDestroy(s.ev1);
@@ -1623,12 +1655,59 @@ void vfgs_hip_reset_state(void)
 	s.seed_epoch++;
 	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
 	s.tables_dirty = true;
+	if (s.ov.active)   // a region left open (a caller that failed between _begin and _end): join it
+	{
+		s.ov.active = false;
+		for (int i = 0; i < 2; i++)
+			if (hipEventRecord(s.ov.join[i], s.ov.s[i]) == hipSuccess) (void)hipStreamWaitEvent(s.ov.user, s.ov.join[i], 0);
+	}
 }
 
 int vfgs_hip_init(int device)
 {
 	std::lock_guard<std::mutex> g(g_mu);
 	return ensure_init(device);
+}
+
+int vfgs_hip_overlap_begin(void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (int e = ensure_init(-1)) return e;
+	State& s = S();
+	if (s.ov.active) return fail(27, "vfgs_hip_overlap_begin: a region is already open");
+	// The two streams must sit on two hardware queues or nothing overlaps.  The runtime deals a fixed number of queues per
+	// priority class to the process's streams in creation order and doubles up beyond it (measured: with one more application
+	// stream alive the two landed on one queue and the region gained nothing); the high-priority class is a pool of its own
+	// that the library is normally alone in, so its first two streams get a queue each.
+	int prio_least = 0, prio_greatest = 0;
+	HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+	for (int i = 0; i < 2; i++)
+	{
+		if (!s.ov.s[i]) HIP_TRY(hipStreamCreateWithPriority(&s.ov.s[i], hipStreamNonBlocking, prio_greatest));
+		if (!s.ov.join[i]) HIP_TRY(hipEventCreateWithFlags(&s.ov.join[i], hipEventDisableTiming));
+	}
+	if (!s.ov.fork) HIP_TRY(hipEventCreateWithFlags(&s.ov.fork, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(s.ov.fork, (hipStream_t)stream));
+	for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(s.ov.s[i], s.ov.fork, 0));
+	s.ov.user = (hipStream_t)stream;
+	s.ov.n = 0;
+	s.ov.active = true;
+	return 0;
+}
+
+int vfgs_hip_overlap_end(void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (int e = ensure_init(-1)) return e;
+	State& s = S();
+	if (!s.ov.active || s.ov.user != (hipStream_t)stream) return fail(27, "vfgs_hip_overlap_end: no region open on this stream");
+	s.ov.active = false;
+	for (int i = 0; i < 2; i++)
+	{
+		HIP_TRY(hipEventRecord(s.ov.join[i], s.ov.s[i]));
+		HIP_TRY(hipStreamWaitEvent(s.ov.user, s.ov.join[i], 0));
+	}
+	return 0;
 }
 
 int vfgs_hip_init_devices(const int* devices, int n)
@@ -1681,7 +1760,7 @@ int vfgs_hip_add_grain_stripe_dev(void* dY, void* dU, void* dV, unsigned y, unsi
 {
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
-	return run_device(dY, dU, dV, dY, dU, dV, width, y, height, y, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+	return run_device(dY, dU, dV, dY, dU, dV, width, y, height, y, height, stride, cstride, 1, 0, 0, pick_stream(stream));
 }
 
 int vfgs_hip_add_grain_frame_dev(void* dY, void* dU, void* dV, unsigned width, unsigned height,
@@ -1689,7 +1768,7 @@ int vfgs_hip_add_grain_frame_dev(void* dY, void* dU, void* dV, unsigned width, u
 {
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
-	return run_device(dY, dU, dV, dY, dU, dV, width, 0, height, 0, height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+	return run_device(dY, dU, dV, dY, dU, dV, width, 0, height, 0, height, stride, cstride, 1, 0, 0, pick_stream(stream));
 }
 
 int vfgs_hip_add_grain_frame_part_dev(void* dY, void* dU, void* dV, unsigned width, unsigned frame_height,
@@ -1699,7 +1778,7 @@ int vfgs_hip_add_grain_frame_part_dev(void* dY, void* dU, void* dV, unsigned wid
 	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
 	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
-	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, 1, 0, 0, (hipStream_t)stream);
+	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, 1, 0, 0, pick_stream(stream));
 }
 
 int vfgs_hip_add_grain_frames_dev(void* dY, void* dU, void* dV, unsigned width, unsigned height, unsigned stride,
@@ -1710,7 +1789,7 @@ int vfgs_hip_add_grain_frames_dev(void* dY, void* dU, void* dV, unsigned width, 
 	S().gen++;
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, height, 0, height, stride, cstride, nframes,
-	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
+	                  y_frame_pitch_bytes, c_frame_pitch_bytes, pick_stream(stream));
 }
 
 int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned width, unsigned frame_height,
@@ -1724,7 +1803,7 @@ int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned wi
 	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
-	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
+	                  y_frame_pitch_bytes, c_frame_pitch_bytes, pick_stream(stream));
 }
 
 int vfgs_hip_add_grain_frames_host(void* const* Y, void* const* U, void* const* V, unsigned nframes, unsigned width,
@@ -1762,7 +1841,7 @@ int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, 
 	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(sY, sU, sV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
-	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream);
+	                  y_frame_pitch_bytes, c_frame_pitch_bytes, pick_stream(stream));
 }
 
 int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV,
@@ -1781,7 +1860,7 @@ int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV,
 	dg.stride = dst_stride; dg.cstride = dst_cstride;
 	dg.ypitch = dst_y_frame_pitch_bytes; dg.cpitch = dst_c_frame_pitch_bytes;
 	return run_device(sY, sU, sV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
-	                  y_frame_pitch_bytes, c_frame_pitch_bytes, (hipStream_t)stream, dg);
+	                  y_frame_pitch_bytes, c_frame_pitch_bytes, pick_stream(stream), dg);
 }
 
 void vfgs_hip_get_seed_state(uint32_t out[4])

@@ -73,7 +73,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #if !defined(VFGS_DEV_BUILD)
 #if VFGS_WAVES != 4 || VFGS_ROWS_PER_WAVE != 4 || VFGS_WG_PER_CU != 4 || VFGS_WG_PER_CU_8BIT_SUB != 3 || VFGS_LDAUX != 0 || VFGS_STAUX != 0 || \
     VFGS_PREFETCH != 1 || VFGS_SCHED_FENCE != 1 || VFGS_SPLIT_INTERLEAVE != 0 || VFGS_ABLATE != 0 || VFGS_ALIGNED != 1 || VFGS_LANE_SHIFT_DPP != 1 || \
-    VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || VFGS_RW_ABLATE != 0 || defined(VFGS_NO_ROWWALK) || \
+    VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || VFGS_RW_ABLATE != 0 || defined(VFGS_NO_ROWWALK) || defined(VFGS_NO_FRONTS) || \
     defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_ALIGN_TEST) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_MIN_FILL_PCT)
 #error "libvfgs_hip: a tuning / ablation knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
@@ -190,6 +190,7 @@ struct KernelArgs {
 	int nblk;                 // 16-sample blocks per line = ceil(width/16), vfgs_hw.c:301
 	int nbrows;               // block rows the stripe touches
 	int nframes;
+	int lfronts;              // row walk: log2 of the frames of a batch that are swept at the same time (their workgroups are dealt out in turn)
 	uint32_t lo2[2], hi2[2];  // clip bounds in sample units (I_min<<bs ...) in both halves of a dword, per plane type (vfgs_hw.c:264-267)
 };
 

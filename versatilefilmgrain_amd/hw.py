@@ -44,6 +44,8 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_add_grain_stripe.argtypes = [vp, vp, vp, u, u, u, u, u]
     lib.vfgs_hip_init.argtypes = [i]
     lib.vfgs_hip_init_devices.argtypes = [C.POINTER(i), i]
+    lib.vfgs_hip_overlap_begin.argtypes = [vp]
+    lib.vfgs_hip_overlap_end.argtypes = [vp]
     lib.vfgs_hip_add_grain_stripe_dev.argtypes = [vp, vp, vp, u, u, u, u, u, vp]
     lib.vfgs_hip_add_grain_frame_dev.argtypes = [vp, vp, vp, u, u, u, u, vp]
     lib.vfgs_hip_add_grain_frame_part_dev.argtypes = [vp, vp, vp, u, u, u, u, u, u, vp]
@@ -86,7 +88,7 @@ EXPORTS = [
     "vfgs_hip_add_grain_frames_dev", "vfgs_hip_add_grain_frames_part_dev", "vfgs_hip_add_grain_copy_dev",
     "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
-    "vfgs_hip_dev_build", "vfgs_hip_init_devices", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
+    "vfgs_hip_dev_build", "vfgs_hip_init_devices", "vfgs_hip_overlap_begin", "vfgs_hip_overlap_end", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
     "vfgs_hip_add_grain_frames_host", "vfgs_hip_host_alloc", "vfgs_hip_host_free",
 ]
 
@@ -195,6 +197,12 @@ class VfgsHip:
 
     def host_free(self, p):
         self.lib.vfgs_hip_host_free(p)
+
+    def overlap_begin(self, stream=0):
+        self._ck(self.lib.vfgs_hip_overlap_begin(stream))
+
+    def overlap_end(self, stream=0):
+        self._ck(self.lib.vfgs_hip_overlap_end(stream))
 
     def init_devices(self, devices):
         """Host-memory frames and stripes are split over these devices from now on (devices[0] stays the library's device)."""
