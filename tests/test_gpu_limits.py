@@ -149,3 +149,28 @@ def test_calls_alternating_between_two_streams(hip):
     torch.cuda.synchronize()
     for i, (d, f) in enumerate(zip(devs, frames)):
         assert d.download().equal_all(f), i
+
+
+@pytest.mark.parametrize("name,lowest", [("fgs_afgs1_test1_8_420", -127), ("fgs_afgs1_test1_8_420", -128), ("fgs_afgs1_test1_10_420", -127),
+                                         ("fgs_afgs1_test1_10_420", -128), ("fgs_afgs1_test1_8_444", -128), ("fgs_sei_10_420", -128)])
+def test_one_pattern_form_with_extreme_pattern_values(hip, name, lowest):
+    """The one-pattern form keeps a negated copy of the pattern (vfgs_layout.h): full-range values +-127 must survive the negation,
+    the edge filter and the overlap blend; a pattern that holds -128 (no negation in a byte; possible through vfgs_set_*_pattern,
+    vfgs_hw.c:314-325, never out of the firmware) makes the host fall back to the general form.  Either way: the oracle's output."""
+    from gpu_util import DevFrame, stream_ptr
+    ora = program(hip, name)
+    depth, sx, sy = T.trace_geometry(T.load_trace(name))
+    rng = np.random.default_rng(5)
+    for k in range(2):                      # slots 0 and 1 of both banks: mostly extremes
+        for setter in ("set_luma_pattern", "set_chroma_pattern"):
+            P = rng.choice(np.array([lowest, lowest, 127, 127, -1, 0, 1, 64], dtype=np.int8), size=4096).astype(np.int8)
+            getattr(hip, setter)(k, P.tobytes())
+            getattr(ora, setter)(k, P.tobytes())
+    f, _ = T.lcg_frames(1936, 112, depth, sx, sy, 2)
+    for fr in f:
+        want = fr.copy()
+        d = DevFrame(fr)
+        hip.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), fr.width, fr.height, fr.stride, fr.cstride, stream_ptr())
+        ora.add_grain_frame(want)
+        assert d.download().equal_all(want)
+    assert hip.seed_state() == ora.seed_state()

@@ -347,7 +347,11 @@ __global__ __launch_bounds__(256) void fw_patch_tables(const PatchArgs p)
 		if (p.one_y)
 		{
 			if (p.slot_y < kSlots && (p.mask_luma >> p.slot_y & 1))
-				dst[r * L.y_rs + x] = (uint8_t)p.bank[(size_t)p.slot_y * 4096 + o];
+			{
+				const int v = p.bank[(size_t)p.slot_y * 4096 + o];       // (generated values are clipped to +-127)
+				dst[r * L.y_rs + x] = (uint8_t)v;
+				dst[L.y_neg + r * L.y_rs + x] = (uint8_t)-v;
+			}
 		}
 		else
 			for (int k = 0; k < kSlots; k++)
@@ -364,7 +368,11 @@ __global__ __launch_bounds__(256) void fw_patch_tables(const PatchArgs p)
 			{
 				const int k = c ? p.slot_cr : p.slot_cb;
 				if (k < kSlots && (p.mask_chroma >> k & 1))
-					p.img[L.c_off[c] + L.c_bank + r * L.c_rs + x] = (uint8_t)p.bank[(size_t)(kSlots + k) * 4096 + r * 64 + x];
+				{
+					const int v = p.bank[(size_t)(kSlots + k) * 4096 + r * 64 + x];
+					p.img[L.c_off[c] + L.c_bank + r * L.c_rs + x] = (uint8_t)v;
+					p.img[L.c_off[c] + L.c_bank + L.c_neg + r * L.c_rs + x] = (uint8_t)-v;
+				}
 			}
 		}
 		else

@@ -664,7 +664,12 @@ void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool
 	for (int r = 0; r < 64; r++)
 		for (int x = 0; x < 64; x++)
 		{
-			if (one_y) yb[r * L.y_rs + x] = slot[0] < vfgs::kSlots ? (uint8_t)s.bank[0][slot[0]][r][x] : 0;
+			if (one_y)
+			{
+				const int v = slot[0] < vfgs::kSlots ? s.bank[0][slot[0]][r][x] : 0;
+				yb[r * L.y_rs + x] = (uint8_t)v;
+				yb[L.y_neg + r * L.y_rs + x] = (uint8_t)-v;      // the negated copy (never -128: one_pattern_ok)
+			}
 			else
 				for (int k = 0; k < vfgs::kSlots; k++) yb[r * L.y_rs + x * vfgs::kSlots + k] = (uint8_t)s.bank[0][k][r][x];
 		}
@@ -674,7 +679,12 @@ void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool
 		for (int r = 0; r < L.ch; r++)
 			for (int x = 0; x < L.cw; x++)
 			{
-				if (one_c) cb[r * L.c_rs + x] = slot[1 + c] < vfgs::kSlots ? (uint8_t)s.bank[1][slot[1 + c]][r][x] : 0;
+				if (one_c)
+				{
+					const int v = slot[1 + c] < vfgs::kSlots ? s.bank[1][slot[1 + c]][r][x] : 0;
+					cb[r * L.c_rs + x] = (uint8_t)v;
+					cb[L.c_neg + r * L.c_rs + x] = (uint8_t)-v;
+				}
 				else
 					for (int k = 0; k < vfgs::kSlots; k++) cb[r * L.c_rs + x * vfgs::kSlots + k] = (uint8_t)s.bank[1][k][r][x];
 			}
@@ -726,7 +736,17 @@ int upload_tables(State& s, hipStream_t stream, bool want_general)
 #ifdef VFGS_NO_ONE_PATTERN      // tools/gpu_variants.sh: always the general form
 	want_general = true;
 #endif
-	const bool one_y = !want_general && slot[0] >= 0, one_c = !want_general && slot[1] >= 0 && slot[2] >= 0;
+	// (the one-pattern form stores a negated copy of the pattern, vfgs_layout.h: not for a pattern that holds -128.  Slots the
+	// firmware generated on the device are clipped to +-127; slot 8 is the all-zero pattern)
+	auto negatable = [&](int pt, int k) {
+		if (k >= vfgs::kSlots || (s.dev_origin[pt] >> k & 1)) return true;
+		const int rows = pt ? 64 / s.csuby : 64, cols = pt ? 64 / s.csubx : 64;
+		for (int r = 0; r < rows; r++)
+			if (memchr(s.bank[pt][k][r], 0x80, cols)) return false;
+		return true;
+	};
+	const bool one_y = !want_general && slot[0] >= 0 && negatable(0, slot[0]);
+	const bool one_c = !want_general && slot[1] >= 0 && slot[2] >= 0 && negatable(1, slot[1]) && negatable(1, slot[2]);
 	if (!s.tables_dirty && s.tables_ring.current() && one_y == s.img_one_y && one_c == s.img_one_c)
 		return 0;
 	if (int e = fw_flush(s, stream)) return e;

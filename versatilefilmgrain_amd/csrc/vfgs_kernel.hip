@@ -123,7 +123,8 @@ struct LaneMap {
 // A block's parameters in ONE register per run (they stay resident for all rows of a wave; k2, the rounding constants and
 // the relative signs of the edge filter are rebuilt from it for every row with a handful of instructions, which is
 // what keeps the kernel at 6 waves per SIMD):
-//   bits 15:0  LDS byte address of bank[.][oy][ox (+ the lane's column for PAIR)][slot 0], row 0 of the block row
+//   bits 15:0  LDS byte address of bank[.][oy][ox (+ the lane's column for PAIR)][slot 0], row 0 of the block row; one-pattern
+//              form, current row of blocks: of the NEGATED bank if the block's sign is negative (grain_unit)
 //   bit  31    the block's sign is negative
 template <int NR>
 struct RunParam {
@@ -162,7 +163,7 @@ __device__ __forceinline__ uint32_t block_param(uint32_t v, uint32_t bank_off, i
 //   F = (l1 + 3 l0 + r0 + 2) >> 2 on true values becomes, in the P~ domain of the lane whose
 //   sample is filtered,  F~ = (a~ + 3 b~ + rel * c~ + (s > 0 ? 2 : 1)) >> 2  with rel = s * s'
 //   the relative sign of the two blocks: for s = -1, -((-A + 2) >> 2) == (A + 1) >> 2.
-template <int DEPTH, int BW, bool OVERLAP, bool ONE, bool ALIGN2>
+template <int DEPTH, int BW, bool OVERLAP, bool ONE, bool ALIGN2, int NEG>
 __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
                                             const RunParam<LaneMap<DEPTH == 8 ? 16 : 8, BW>::NR>& rp,
                                             const RunParam<LaneMap<DEPTH == 8 ? 16 : 8, BW>::NR>& up,
@@ -183,8 +184,10 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	for (int r = 0; r < NR; r++)
 	{
 		sg[r] = (int)rp.pa[r] >> 31;
-		ad[r] = (rp.pa[r] & 0xffffu) + rowoff;
-		k2s[r] = OVERLAP ? lutb : (((uint32_t)sg[r] & 0x04000400u) | lutb);     // OVERLAP: the +scale table
+		// one-pattern form: the address of a negative block (of the CURRENT row of blocks; `up` is only used on overlap lines)
+		// points into the negated bank (vfgs_layout.h); the overlap lines blend true values by signed weights: back to the bank
+		ad[r] = (rp.pa[r] & 0xffffu) + rowoff - ((ONE && OVERLAP) ? ((uint32_t)sg[r] & (uint32_t)NEG) : 0u);
+		k2s[r] = ONE ? 0u : ((OVERLAP || (VFGS_XABLATE & 1)) ? lutb : (((uint32_t)sg[r] & 0x04000400u) | lutb));     // OVERLAP: the +scale table
 	}
 	uint32_t e[NS];
 	int P[NS];
@@ -235,7 +238,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 			else
 				d = *(const uint32_t*)(lds + adq + M::col(q));
 #pragma unroll
-			for (int i = 0; i < 4; i++) out[i] = (int)(d << (24 - 8 * i)) >> 24;
+			for (int i = 0; i < 4; i++) out[i] = (VFGS_XABLATE & 4) ? (int)d + i : (int)(d << (24 - 8 * i)) >> 24;
 		}
 		else
 		{
@@ -276,13 +279,14 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	// 3-tap filter across the block edge (vfgs_hw.c:250-259), on unfiltered neighbours
 	// (all values are small: explicit 24-bit multiply-adds; the compiler otherwise reaches for 32/64-bit
 	// multiplies and turns the selects into a branch that copies all the P registers)
-	if (M::PAIR)
+	if (VFGS_XABLATE & 16) {}
+	else if (M::PAIR)
 	{
 		const int mine = first ? P[0] : P[7];
 		const int inner = first ? P[1] : P[6];
 		const int theirs = swap_lane_pairs(mine);
 		int f;
-		if (OVERLAP) f = (theirs + mad_vvv(3, mine, inner + 2)) >> 2;
+		if (OVERLAP || ONE) f = (theirs + mad_vvv(3, mine, inner + 2)) >> 2;
 		else
 		{
 			const int x = sg[0] ^ swap_lane_pairs(sg[0]);                    // 0: the two blocks have the same sign, -1: opposite
@@ -299,7 +303,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		for (int ed = 0; ed < M::NE; ed++)
 		{
 			const int s = 4 * M::edge_quad(ed);              // l1 = P[s+2], l0 = P[s+3] | r0 = P[s+4], r1 = P[s+5]
-			if (OVERLAP)
+			if (OVERLAP || ONE)
 			{
 				fl[ed] = (P[s + 4] + mad_vvv(3, P[s + 3], P[s + 2] + 2)) >> 2;
 				fr[ed] = (P[s + 3] + mad_vvv(3, P[s + 4], P[s + 5] + 2)) >> 2;
@@ -330,8 +334,11 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		if (DEPTH > 8)  // a 16-bit container may hold anything: keep the add inside int16 (result is clipped anyway)
 			v = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, v), __builtin_bit_cast(u16x2, 0x70007000u)));
 		s16x2 s = __builtin_bit_cast(s16x2, v) + __builtin_bit_cast(s16x2, gp);
-		s = __builtin_elementwise_max(s, __builtin_bit_cast(s16x2, lo2));
-		s = __builtin_elementwise_min(s, __builtin_bit_cast(s16x2, hi2));
+		if (!(VFGS_XABLATE & 2))
+		{
+			s = __builtin_elementwise_max(s, __builtin_bit_cast(s16x2, lo2));
+			s = __builtin_elementwise_min(s, __builtin_bit_cast(s16x2, hi2));
+		}
 		return __builtin_bit_cast(uint32_t, s);
 	};
 	if (DEPTH > 8)
@@ -414,7 +421,7 @@ __device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, uint32_t
 	else if (N == 1) __builtin_amdgcn_raw_buffer_store_b32(w[0], rs, voff, soff, AUX);
 }
 
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, int IMG_BYTES, bool ONE, bool AL>
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, int IMG_BYTES, bool ONE, bool AL, int NEG>
 __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, int r,
                                           const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
 {
@@ -635,7 +642,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 		{
 			const uint32_t v = __builtin_amdgcn_alignbit(wcur[g][rr].y, wcur[g][rr].x, (cur_bit + (uint32_t)blk[g][rr]) & 31);
 			bool neg;
-			const uint32_t ad = block_param<SUBX, SUBY, RS, ONE>(v, bank_off, fsx, fsy, fsb, &neg) + pairoff;
+			const uint32_t ad = block_param<SUBX, SUBY, RS, ONE>(v, bank_off, fsx, fsy, fsb, &neg) + pairoff + ((ONE && neg) ? (uint32_t)NEG : 0u);
 			rp[g].pa[rr] = ad | (neg ? 0x80000000u : 0u);
 		}
 
@@ -657,7 +664,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 #endif
 			uint32_t t[4] = {w[g][0], w[g][1], w[g][2], w[g][3]};
 			if (PARTIAL && anypart[g]) rotate_partial(g, t);
-			grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
+			grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2, NEG>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
 			if (OUT8)
 			{
 				uint32_t n[4];
@@ -725,7 +732,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 			for (int d = K; d < 4; d++) t[d] = w[g][d - K];
 			load_seg<LDA>(nrs, vo[g], rowb + rstep, w[g]);
 			if (g == 0) load_dwords<K, LDA>(nrs, preoff, rowb + rstep, pre);
-			grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
+			grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2, NEG>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
 			if (g == 0)
 			{
 				store_dwords<K, STA>(drs, preoff, drowb, t);               // lane 0: the tail of the unit in front of the tile
@@ -809,7 +816,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 //     units are stored one step later, once lane 0 of the next segment has delivered the last dwords of its lane 63;
 //   * row bases and segment offsets live in the buffer descriptor (base, num_records = bytes of the row left), so the
 //     hardware range check covers every access of every lane: lanes behind the row's end load 0 and store nothing.
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE>
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE, int NEG>
 __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, const int r,
                                              const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
 {
@@ -926,7 +933,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 		const uint32_t blk = (uint32_t)min(max(e - 1, 0), last);
 		bool neg;
 		const uint32_t vc = __builtin_amdgcn_alignbit(wc[i].y, wc[i].x, (cur_bit + blk) & 31);
-		const uint32_t pc = block_param<SUBX, SUBY, RS, ONE>(vc, bank_off, fsx, fsy, fsb, &neg) | (neg ? 0x80000000u : 0u);
+		const uint32_t pc = (block_param<SUBX, SUBY, RS, ONE>(vc, bank_off, fsx, fsy, fsb, &neg) + ((ONE && neg) ? (uint32_t)NEG : 0u)) | (neg ? 0x80000000u : 0u);
 		const uint32_t vu = __builtin_amdgcn_alignbit(wu[i].y, wu[i].x, (up_bit + blk) & 31);
 		const uint32_t pu = block_param<SUBX, SUBY, RS, ONE>(vu, bank_off, fsx, fsy, fsb, &neg) | (neg ? 0x80000000u : 0u);
 		if (e < kParamEntries)
@@ -948,10 +955,17 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	const int cl = M::PAIR ? lane - 1 - (lane & 1) : lane * LPB - 1;       // PAIR: left unit of my lane pair; else: block of run 0 (both for segment 0)
 	constexpr int SSTEP = M::PAIR ? 64 : BPS;                              // what `cl` advances by per segment
 	// DPP moves by one lane; lanes without a source lane (lane 0 / lane 63) keep `old`; the rotations wrap around
+#if VFGS_XABLATE & 8
+	auto lane_up = [](uint32_t old, uint32_t v) { return v; };
+	auto lane_down = [](uint32_t old, uint32_t v) { return v; };
+	auto rot_up = [](uint32_t v) { return v; };
+	auto rot_down = [](uint32_t v) { return v; };
+#else
 	auto lane_up = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false); };    // wave_shr:1: lane l <- lane l - 1
 	auto lane_down = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130, 0xf, 0xf, false); };  // wave_shl:1: lane l <- lane l + 1
 	auto rot_up = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13c, 0xf, 0xf, false); };      // wave_ror:1: lane 0 <- lane 63
 	auto rot_down = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134, 0xf, 0xf, false); };    // wave_rol:1: lane 63 <- lane 0
+#endif
 
 	// ---- the walk ----------------------------------------------------------------------------------------------------
 	uint32_t carry[4] = {0, 0, 0, 0};      // in lane 0: the last K dwords of lane 63 of the previous segment of the row
@@ -1016,7 +1030,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 					for (int rr = 0; rr < NR; rr++) rp.pa[rr] = *(const uint32_t*)(pe + PT_CUR + (u * BPS + rr) * 4) + pairoff;
 #pragma unroll
 					for (int rr = 0; rr < NR; rr++) up.pa[rr] = OV ? *(const uint32_t*)(pe + PT_UP + (u * BPS + rr) * 4) + pairoff : 0u;
-					grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2>(lds, t, rp, up, lutb, rowoff, uprowoff, OV ? wc_ : 0, OV ? wu_ : 0, edge_on, first, lo2, hi2);
+					grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, OV ? wc_ : 0, OV ? wu_ : 0, edge_on, first, lo2, hi2);
 				}
 				// the previous segment's units are complete once the K dwords its lanes computed have moved one lane down; its
 				// lane 63 takes them from my lane 0 (the previous segment of a row's first one is the last of another row:
@@ -1067,13 +1081,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * wg_per_cu<DEPTH, C
 	const int f = blockIdx.y;            // grid: x = workgroup inside the frame, y = frame of the batch
 	int r = blockIdx.x;
 	if (r < a.pd[0].wgs)
-		run_plane<DEPTH, 16, 1, 1, L.y_rs, OUT8, L.y_bytes, ONEY, AL>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+		run_plane<DEPTH, 16, 1, 1, L.y_rs, OUT8, L.y_bytes, ONEY, AL, L.y_neg>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
 		const int comp = 1 + (r >= a.pd[1].wgs);
 		if (comp == 2) r -= a.pd[1].wgs;
-		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, OUT8, L.c_bytes, ONEC, AL>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, OUT8, L.c_bytes, ONEC, AL, L.c_neg>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 	}
 }
 
@@ -1093,13 +1107,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3
 	int r = (int)(blockIdx.x >> a.lfronts);
 	if (f >= a.nframes) return;
 	if (r < a.pd[0].wgs)
-		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
 		const int comp = 1 + (r >= a.pd[1].wgs);
 		if (comp == 2) r -= a.pd[1].wgs;
-		run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+		run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 	}
 }
 

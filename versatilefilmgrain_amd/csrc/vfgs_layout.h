@@ -66,6 +66,10 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #define VFGS_RW_ABLATE 0      // row-walk kernels: 0 = product; 1..3 timing-only variants with WRONG output (tools/dev/build_variant.sh)
 #endif
 
+#ifndef VFGS_XABLATE
+#define VFGS_XABLATE 0        // bit mask of timing-only probes with WRONG output (what would an instruction saved be worth?): 1 = no sign table
+#endif                        // select, 2 = no clip, 4 = pattern bytes not extracted, 8 = no lane rotation, 16 = no edge filter
+
 // The product is built with every knob at its default (versatilefilmgrain_amd/build.py passes none).  The developer tools that
 // time variants (tools/dev/build_variant.sh, tools/gpu_variants.sh, tools/ablate.py) define VFGS_DEV_BUILD; without it any
 // other value is a build error, so a stray -D cannot produce a library that silently computes something else -- and a
@@ -73,7 +77,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #if !defined(VFGS_DEV_BUILD)
 #if VFGS_WAVES != 4 || VFGS_ROWS_PER_WAVE != 4 || VFGS_WG_PER_CU != 4 || VFGS_WG_PER_CU_8BIT_SUB != 3 || VFGS_LDAUX != 0 || VFGS_STAUX != 0 || \
     VFGS_PREFETCH != 1 || VFGS_SCHED_FENCE != 1 || VFGS_SPLIT_INTERLEAVE != 0 || VFGS_ABLATE != 0 || VFGS_ALIGNED != 1 || VFGS_LANE_SHIFT_DPP != 1 || \
-    VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || VFGS_RW_ABLATE != 0 || defined(VFGS_NO_ROWWALK) || defined(VFGS_NO_FRONTS) || \
+    VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || VFGS_RW_ABLATE != 0 || VFGS_XABLATE != 0 || defined(VFGS_NO_ROWWALK) || defined(VFGS_NO_FRONTS) || \
     defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_ALIGN_TEST) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_MIN_FILL_PCT)
 #error "libvfgs_hip: a tuning / ablation knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
@@ -104,7 +108,12 @@ constexpr int kParamBytes = 2 * kParamTableBytes;
 //
 // ONE-PATTERN form: when a component's pattern LUT selects the same slot for every intensity (all AFGS1 models, the
 // single-pattern SEI models, the chroma of the default SEI model) only that pattern is stored, one byte per sample, rows
-// padded by 16 bytes; four samples are one dword.  An eighth of the LDS traffic and of the LDS footprint.
+// padded by 16 bytes; four samples are one dword.  An eighth of the LDS traffic and of the LDS footprint.  The bank is
+// followed by its NEGATED copy (y_neg / c_neg bytes further on): a block's random sign then is a choice of bank, made once
+// per block and row in the address, the values that come out of LDS are the true signed grain (plain edge filter, no
+// relative signs) and every sample uses the +scale table at LDS offset 0 (no table select in the gather address).  The host
+// only chooses this form for patterns without the value -128, which has no negation in a byte (the firmware's generators
+// clip to +-127, vfgs_fw.c:321-323,494).
 //
 // LUT (one dword per 8-bit intensity; per component TWO tables of 256 entries, the first with
 // +scale, the second with -scale, so that a block's random sign is applied by choosing the table
@@ -118,6 +127,7 @@ struct ImageLayout {
 	int lut_bytes;              // one component: +scale table, -scale table
 	int y_rs, c_rs;             // bank row strides, bytes
 	int y_bank, c_bank;         // offsets of the banks inside their sub-images (= LDS offsets)
+	int y_neg, c_neg;           // one-pattern form: bytes from a bank to its negated copy (0 in the general form)
 	int y_bytes, c_bytes;       // sizes of the sub-images (chroma: of ONE chroma sub-image)
 	int y_off, c_off[2];        // offsets of the sub-images of Y, Cb, Cr in the device image
 	int c_lut[2];               // LDS offset of Cb's / Cr's LUT pair inside its sub-image
@@ -136,8 +146,10 @@ constexpr ImageLayout image_layout(int csubx, int csuby, bool one_y, bool one_c)
 	L.c_rs = one_c ? L.cw + 16 : L.cw * kSlots + 16;
 	L.y_bank = L.lut_bytes;
 	L.c_bank = one_c ? L.lut_bytes : 2 * L.lut_bytes;
-	L.y_bytes = L.y_bank + 64 * L.y_rs;
-	L.c_bytes = L.c_bank + L.ch * L.c_rs;
+	L.y_neg = one_y ? 64 * L.y_rs : 0;
+	L.c_neg = one_c ? L.ch * L.c_rs : 0;
+	L.y_bytes = L.y_bank + 64 * L.y_rs + L.y_neg;
+	L.c_bytes = L.c_bank + L.ch * L.c_rs + L.c_neg;
 	L.y_off = 0;
 	L.c_off[0] = L.y_bytes;
 	L.c_off[1] = one_c ? L.y_bytes + L.c_bytes : L.y_bytes;
