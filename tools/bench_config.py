@@ -45,6 +45,8 @@ def main():
                     help="inplace (default); copy: out of place, same depth; copy8: 10-bit in, 8-bit out (the CLI's --outdepth 8 fused into the store)")
     ap.add_argument("--overlap", action="store_true", help="time the calls inside one vfgs_hip_overlap_begin/_end region (independent frames, one per call)")
     ap.add_argument("--streams", type=int, default=1, help="experiment: issue consecutive launches round-robin on this many streams (they may overlap)")
+    ap.add_argument("--pool", type=int, default=0, help="buffer sets cycled through (default: enough for > 1.5 GB)")
+    ap.add_argument("--single-alloc", action="store_true", help="each set is ONE allocation [Y frames | U frames | V frames] (bench.py's layout)")
     ap.add_argument("--width", type=int, default=0, help="override the picture width (experiments)")
     ap.add_argument("--height", type=int, default=0, help="override the picture height (experiments)")
     args = ap.parse_args()
@@ -63,6 +65,8 @@ def main():
     frame_bytes = sz * (w * hh + 2 * (w // sx) * (hh // sy))
     pool = max(3, int(1.5e9 // (frame_bytes * args.batch)) + 1)       # cycle through > 1.5 GB: nothing is served by the Infinity Cache
     pool = min(pool, 64)
+    if args.pool:
+        pool = args.pool
 
     def mk(rows, cols):
         if args.content == "ramp":
@@ -74,7 +78,14 @@ def main():
             noise = torch.randint(-4, 5, (args.batch, rows, cols), dtype=torch.int32, device="cuda", generator=g)
             return (base + noise).clamp(0, (1 << depth) - 1).to(dt)
         return torch.randint(0, 1 << depth, (args.batch, rows, cols), dtype=torch.int32, device="cuda", generator=g).to(dt)
-    sets = [(mk(hh, w), mk(hh // sy, w // sx), mk(hh // sy, w // sx)) for _ in range(pool)]
+    if args.single_alloc:
+        sets = []
+        for _ in range(pool):
+            ny, nc = args.batch * hh * w, args.batch * (hh // sy) * (w // sx)
+            b = torch.randint(0, 1 << depth, (ny + 2 * nc,), dtype=torch.int32, device="cuda", generator=g).to(dt)
+            sets.append((b[:ny].view(args.batch, hh, w), b[ny:ny + nc].view(args.batch, hh // sy, w // sx), b[ny + nc:].view(args.batch, hh // sy, w // sx)))
+    else:
+        sets = [(mk(hh, w), mk(hh // sy, w // sx), mk(hh // sy, w // sx)) for _ in range(pool)]
     st = torch.cuda.current_stream().cuda_stream
     extra_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
     stream_of = (lambda i: extra_streams[i % len(extra_streams)].cuda_stream) if extra_streams else (lambda i: st)

@@ -11,6 +11,7 @@ for c in 0 1 2 3 4 5 6; do
   for b in 1 8; do
     python3 tools/bench_config.py --config $c --batch $b >> $R/r03_config_lines.jsonl 2>> $R/r03_config.err
   done
+  python3 tools/bench_config.py --config $c --batch 1 --steps 400 --overlap >> $R/r03_config_lines.jsonl 2>> $R/r03_config.err     # one frame per call inside an overlap region
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/cfgprof_$c -- python3 $GRAFT_REPO_ROOT/tools/bench_config.py --config $c --batch 8 > $R/cfgprof_$c.log 2>&1 )
 done
 cat $R/r03_config_lines.jsonl
@@ -26,3 +27,6 @@ json.dump(rows, open('gpurun_out/r03_config_kernel_stats.json', 'w'), indent=1)
 print(json.dumps(rows, indent=1))
 PY
 python3 tools/host_pipeline_bench.py > $R/r03_host_pipeline.jsonl 2>/dev/null; python3 tools/host_pipeline_bench.py --devices 0,0 >> $R/r03_host_pipeline.jsonl 2>/dev/null; cat $R/r03_host_pipeline.jsonl
+
+# the same one-frame-per-call pattern from a C caller (no ctypes in the way): host us per call, device us per frame
+( for g in "1920 1080 4000" "3840 2160 2000" "7680 4320 600"; do timeout -k 10 120 tools/bin/host_call_bench $g; done ) > $R/r03_host_call_bench.jsonl 2>&1; cat $R/r03_host_call_bench.jsonl

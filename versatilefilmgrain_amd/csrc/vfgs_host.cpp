@@ -1701,6 +1701,9 @@ int vfgs_hip_overlap_begin(void* stream)
 	// that the library is normally alone in, so its first two streams get a queue each.
 	int prio_least = 0, prio_greatest = 0;
 	HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+#ifdef VFGS_DEV_BUILD      // A/B of the priority class (tools/dev): VFGS_OV_PRIO=normal|low
+	if (const char* e = getenv("VFGS_OV_PRIO")) prio_greatest = e[0] == 'n' ? 0 : (e[0] == 'l' ? prio_least : prio_greatest);
+#endif
 	for (int i = 0; i < 2; i++)
 	{
 		if (!s.ov.s[i]) HIP_TRY(hipStreamCreateWithPriority(&s.ov.s[i], hipStreamNonBlocking, prio_greatest));

@@ -214,6 +214,13 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		else
 		{
 			const uint32_t v = w[q], k1 = k2 & 0xffffu;
+#if VFGS_XABLATE & (64 | 128)     // probe: the table replicated over 8 / 16 banks (addresses only; WRONG values)
+			constexpr int LR = (VFGS_XABLATE & 64) ? 3 : 4;
+			const uint32_t lanec = ((threadIdx.x & ((1u << LR) - 1)) << 2) | (k1 & 0);
+#pragma unroll
+			for (int i = 0; i < 4; i++) e[4 * q + i] = *(const uint32_t*)(lds + (((((v >> (8 * i)) & 0xffu) << (2 + LR)) | lanec) & 0x3fffu));
+			if (false)
+#endif
 			e[4 * q + 0] = *(const uint32_t*)(lds + (((v << 2) & 0x3fcu) | k1));
 			e[4 * q + 1] = *(const uint32_t*)(lds + (((v >> 6) & 0x3fcu) | k1));
 			e[4 * q + 2] = *(const uint32_t*)(lds + (((v >> 14) & 0x3fcu) | k1));
@@ -245,7 +252,13 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 #if VFGS_ABLATE == 9
 			const u32x4 c0 = {adq, adq * 3, adq * 5, adq * 7}, c1 = {adq ^ 77, adq + 99, adq * 9, adq * 11};
 #else
+#if VFGS_XABLATE & 32      // probe: four 8-byte reads instead of two 16-byte reads at 8-byte aligned addresses
+			const u32x2* hp = (const u32x2*)__builtin_assume_aligned(lds + adq + M::col(q) * kSlots, 8);
+			const u32x2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
+			const u32x4 c0 = {h0.x, h0.y, h1.x, h1.y}, c1 = {h2.x, h2.y, h3.x, h3.y};
+#else
 			const u32x4 c0 = *(const u32x4*)(lds + adq + M::col(q) * kSlots), c1 = *(const u32x4*)(lds + adq + M::col(q) * kSlots + 16);
+#endif
 #endif
 			out[0] = pick_slot(c0.y, c0.x, e[4 * q + 0]); out[1] = pick_slot(c0.w, c0.z, e[4 * q + 1]);
 			out[2] = pick_slot(c1.y, c1.x, e[4 * q + 2]); out[3] = pick_slot(c1.w, c1.z, e[4 * q + 3]);
@@ -1092,8 +1105,15 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * wg_per_cu<DEPTH, C
 }
 
 // row-walk kernel (run_plane_rw): in place or out of place, same sample size; workgroups numbered frame -> plane -> block row -> part
+// Waves per SIMD the row-walk kernels are allocated for.  The 8-bit all-one-pattern kernels need 97..100 registers, one
+// allocation granule above the 96 of five waves: asking for five costs one register spilled in the prologue and reloaded
+// once per row (not in the group loop) and is worth 3 % (profiles/r03_ab22_lds_probes_and_occupancy.log); the general-form
+// kernels are held at four by their LDS image, the others by spills.
+template <int DEPTH, bool ONEY, bool ONEC>
+constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && VFGS_WG_PER_CU == 4) ? 5 : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
+
 template <int DEPTH, int CSUBX, int CSUBY, bool ONEY, bool ONEC>
-__global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4) void grain_rw_kernel(const KernelArgs a)
+__global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC>())) void grain_rw_kernel(const KernelArgs a)
 {
 	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes + kParamBytes];
