@@ -129,3 +129,32 @@ def test_overlap_region_errors():
         h.overlap_end(other.cuda_stream)  # not the region's stream
     h.overlap_end(st)
     torch.cuda.synchronize()
+
+
+def test_overlap_region_with_configuration_changes_between_frames():
+    """A new model (banks, LUTs, seed: a per-picture SEI / AFGS1 message) before every frame of a region: the table and LFSR
+    images uploaded for a frame on one internal stream must be complete before the kernel on the other one reads them, and an
+    image still being read there must not be overwritten (the slot guards of vfgs_host.cpp)."""
+    import torch
+    from gpu_util import DevFrame
+    from versatilefilmgrain_amd import hw
+
+    h = hw.VfgsHip(device=0)
+    names = ["fgs_sei_10_420", "fgs_sei_ff_test6_10_420", "fgs_afgs1_test1_10_420", "fgs_sei_ar_test1_10_420"] * 4
+    frames, _ = T.lcg_frames(1936, 528, 10, 2, 2, len(names))
+    devs = [DevFrame(f) for f in frames]
+    torch.cuda.synchronize()
+    ora = T.OracleHW()
+    st = torch.cuda.current_stream().cuda_stream
+    h.overlap_begin(st)
+    for name, d, f in zip(names, devs, frames):
+        rec = T.load_trace(name)
+        T.replay(h, rec)
+        T.replay(ora, rec)
+        h.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), f.width, f.height, f.stride, f.cstride, st)
+        ora.add_grain_frame(f)
+    h.overlap_end(st)
+    torch.cuda.synchronize()
+    for i, (d, f) in enumerate(zip(devs, frames)):
+        assert d.download().equal_all(f), i
+    assert h.seed_state() == ora.seed_state()
