@@ -155,8 +155,15 @@ def main():
     if world > 1:
         # The data path has no collective (stripes are independent, DESIGN.md "multi-GPU"): the process group only
         # carries the barrier around the timed region and the max / gather of the timings -- host-side, over gloo.
+        # (gloo announces its connections on fd 1, from C++, whenever it makes them: the contract is ONE line on stdout, so the
+        # process's fd 1 is pointed at stderr for the rest of the run and the JSON line goes to the saved descriptor)
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         dist.init_process_group("gloo")
 
+    else:
+        json_out = sys.stdout
     h = hw.VfgsHip(device=local)
     T.replay(h, T.load_trace(TRACE))     # programs banks/LUTs/shift/depth/subsampling/seed 12345
 
@@ -367,7 +374,7 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
