@@ -223,7 +223,7 @@ def main():
     # next one's head).  Kernels overlap here, so a per-kernel duration (rocprof) no longer measures throughput; the figure
     # is bytes / wall time of the region on the device.
     region = None
-    region_launches = max(args.steps, 48)     # (the region's first and last launch run alone: a short region is mostly edges)
+    region_launches = max(args.steps, 100)     # (the region's first and last launch run alone: a short region is mostly edges)
     if not args.no_region:
         for _ in range(2):      # (the first region creates the internal streams and their queues)
             h.overlap_begin(stream)

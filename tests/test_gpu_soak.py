@@ -16,6 +16,8 @@ CASES = [
     ("fgs_sei_10_420", 7680, 4320, 2, "part"),          # bench.py's shape: 7680x4320 10-bit 4:2:0, fgs_sei, 8 frames per launch
     ("fgs_sei_10_420", 7680, 4320, 3, "part_region"),   # the same launches inside an overlap region (two run at a time, one frame front each)
     ("fgs_sei_10_420", 7680, 4320, 1, "part3"),         # odd frame count: the two frame fronts of one launch, last front half empty
+    ("fgs_afgs1_test1_8_420", 7680, 4320, 1, "part3"),  # two frame fronts in the 8-bit one-pattern kernels (negated banks, five waves per SIMD)
+    ("fgs_sei_10_420", 7680, 4320, 1, "copy3"),         # two frame fronts, out of place
     ("fgs_afgs1_test1_8_444", 3840, 2160, 2, "frames"),  # BASELINE config 4
     ("fgs_afgs1_test1_8_420", 3840, 2160, 2, "frames"),  # the mainstream AFGS1 case (8-bit 4:2:0, vfgs_hw.c:352-362)
     ("fgs_sei_8_420", 3840, 2160, 1, "frames"),          # 8-bit 4:2:0 with per-sample pattern selection
@@ -37,7 +39,7 @@ def test_queued_full_size_batches_equal_oracle(name, w, hh, launches, entry):
     dt = torch.int16 if depth > 8 else torch.uint8
     npd = np.uint16 if depth > 8 else np.uint8
     sz = 2 if depth > 8 else 1
-    batch = 3 if entry == "part3" else 8
+    batch = 3 if entry in ("part3", "copy3") else 8
     stride, cstride = w, w // sx
     g = torch.Generator(device="cuda").manual_seed(11)
     mk = lambda r, c: torch.randint(0, 1 << depth, (batch, r, c), dtype=torch.int32, device="cuda", generator=g).to(dt)
@@ -47,7 +49,14 @@ def test_queued_full_size_batches_equal_oracle(name, w, hh, launches, entry):
     if entry == "part_region":
         h.overlap_begin(st)
     for Y, U, V in sets:      # all launches queued back to back, nothing in between
-        if entry in ("part", "part3", "part_region"):
+        if entry == "copy3":
+            dst = tuple(torch.zeros_like(t) for t in (Y, U, V))
+            h.add_grain_copy_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), dst[0].data_ptr(), dst[1].data_ptr(), dst[2].data_ptr(), w, hh, 0, hh,
+                                 stride, cstride, batch, Y[0].numel() * sz, U[0].numel() * sz, st)
+            torch.cuda.synchronize()
+            assert all(torch.equal(t, torch.from_numpy(s_.view(np.int16 if depth > 8 else np.uint8)).cuda()) for t, s_ in zip((Y, U, V), src[0])), "source changed"
+            Y.copy_(dst[0]); U.copy_(dst[1]); V.copy_(dst[2])
+        elif entry in ("part", "part3", "part_region"):
             h.add_grain_frames_part_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, 0, hh, stride, cstride, batch,
                                         Y[0].numel() * sz, U[0].numel() * sz, st)
         else:

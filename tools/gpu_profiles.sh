@@ -12,6 +12,7 @@ for c in 0 1 2 3 4 5 6; do
     python3 tools/bench_config.py --config $c --batch $b >> $R/r03_config_lines.jsonl 2>> $R/r03_config.err
   done
   python3 tools/bench_config.py --config $c --batch 1 --steps 400 --overlap >> $R/r03_config_lines.jsonl 2>> $R/r03_config.err     # one frame per call inside an overlap region
+  python3 tools/bench_config.py --config $c --batch 8 --overlap >> $R/r03_config_lines.jsonl 2>> $R/r03_config.err                 # 8 frames per call inside an overlap region
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/cfgprof_$c -- python3 $GRAFT_REPO_ROOT/tools/bench_config.py --config $c --batch 8 > $R/cfgprof_$c.log 2>&1 )
 done
 cat $R/r03_config_lines.jsonl
