@@ -171,7 +171,8 @@ int vfgs_hip_timer_end(void* stream, float* elapsed_ms);
  * `stream` after _begin; the library runs them alternately on two internal streams forked from `stream` at _begin and joined
  * back into it at _end (events only there, nothing between the launches).  Work queued on `stream` before _begin is complete
  * before the first call starts; work queued after _end sees every result.  Results and seed registers are those of the same
- * calls without the region.  One region at a time.  0 or an error code. */
+ * calls without the region.  One region at a time.  0 or an error code.  (The first region of a process creates the two
+ * internal streams and their hardware queues: about 10 ms, once.) */
 int vfgs_hip_overlap_begin(void* stream);
 int vfgs_hip_overlap_end(void* stream);
 
