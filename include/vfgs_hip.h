@@ -154,6 +154,10 @@ void vfgs_hip_get_seed_state(uint32_t out[4]);
  * out[8] = { scale_shift as stored (vfgs_hw.c:56: shift + 6 - bs), bs, Y min, Y max, C min, C max, csubx, csuby }. */
 int vfgs_hip_get_luts(int c, unsigned char scale[256], unsigned char pattern[256]);
 void vfgs_hip_get_params(int out[8]);
+/* ... and of the device copy of the LFSR bit stream (the reference steps its registers, vfgs_hw.c:74-79,309-310; here a window of the
+ * stream lives in device memory): out[4] = { windows uploaded in a caller's stream (a bubble between two of its kernels), windows
+ * built ahead on the library's copy stream, switches to a window built ahead, 32-bit words of the current window }. */
+void vfgs_hip_get_stream_stats(uint64_t out[4]);
 
 /* Last error of a vfgs_hip_* call (0 = none) and its text. */
 int vfgs_hip_last_error(void);

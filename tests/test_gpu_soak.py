@@ -167,3 +167,46 @@ def test_overlap_region_with_configuration_changes_between_frames():
     for i, (d, f) in enumerate(zip(devs, frames)):
         assert d.download().equal_all(f), i
     assert h.seed_state() == ora.seed_state()
+
+
+def test_lfsr_window_lookahead_across_refills():
+    """A seed that is never reset over 128 frames of 7680x4320 consumes 16.6 Mbit of the LFSR stream: the device window grows to its
+    full 1 MiB, the NEXT window is built ahead on the library's copy stream once a call reaches the second half, and a later call
+    switches to it (vfgs_host.cpp StreamCache::ensure).  Every frame of every launch against the oracle; two launches are always in
+    flight (the second one is queued before the first is checked), so a window swapped too early would be seen."""
+    import torch
+    from versatilefilmgrain_amd import hw
+
+    h = hw.VfgsHip(device=0)
+    st = torch.cuda.current_stream().cuda_stream
+    rec = T.load_trace("fgs_sei_10_420")
+    T.replay(h, rec)
+    ora = T.OracleHW()
+    T.replay(ora, rec)
+    w, hh, batch, launches = 7680, 4320, 8, 16
+    g = torch.Generator(device="cuda").manual_seed(23)
+    mk = lambda r, c: torch.randint(0, 1024, (batch, r, c), dtype=torch.int32, device="cuda", generator=g).to(torch.int16)
+
+    def launch():
+        Y, U, V = mk(hh, w), mk(hh // 2, w // 2), mk(hh // 2, w // 2)
+        src = tuple(t.cpu().numpy().view(np.uint16) for t in (Y, U, V))
+        h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, w, w // 2, batch, Y[0].numel() * 2, U[0].numel() * 2, st)
+        return (Y, U, V), src
+
+    bad = []
+    pending = launch()
+    for li in range(launches):
+        nxt = launch() if li + 1 < launches else None
+        (Y, U, V), (sY, sU, sV) = pending
+        gY, gU, gV = (t.cpu().numpy().view(np.uint16) for t in (Y, U, V))
+        for f in range(batch):
+            fr = T.Frame(w, hh, 10, 2, 2, stride=w, cstride=w // 2)
+            fr.Y[:hh], fr.U[:hh // 2], fr.V[:hh // 2] = sY[f], sU[f], sV[f]
+            ora.add_grain_frame(fr)
+            if not (np.array_equal(fr.Y[:hh], gY[f]) and np.array_equal(fr.U[:hh // 2], gU[f]) and np.array_equal(fr.V[:hh // 2], gV[f])):
+                bad.append((li, f))
+        pending = nxt
+    assert not bad, f"frames (launch, index) that differ from the oracle: {bad}"
+    assert h.seed_state() == ora.seed_state()
+    stats = h.stream_stats()
+    assert stats["windows_built_ahead"] >= 1 and stats["switches_to_built_ahead"] >= 1, stats

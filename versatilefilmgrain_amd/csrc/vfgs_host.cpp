@@ -181,7 +181,8 @@ public:
 		ck_word_ = 0;
 		ck_reg_ = reg;
 		if (cur_ >= 0) (void)slot_[cur_].guard.leave();    // kernels queued so far still read it
-		cur_ = -1;   // nothing valid; slots keep their allocations
+		if (next_ >= 0) (void)slot_[next_].guard.leave();  // a window prepared ahead belongs to the old seed (its upload may still run)
+		cur_ = next_ = -1;   // nothing valid; slots keep their allocations
 		// A new seed per frame is the normal case for AFGS1 (vfgs_fw.c:672), so the first window after a
 		// reseed is only as large as the call needs; a stream that keeps being consumed grows its refills.
 		refill_ = kFirstRefill;
@@ -220,21 +221,96 @@ public:
 	}
 
 	// make the device image cover absolute bits [lo, hi + 64); returns 0 or a HIP error
+	//
+	// A refill in the caller's stream is a bubble between two of its kernels (1 MiB host -> device: ~35 us per 64 frames of
+	// 4320p, 1-2 % of a saturated stream: profiles/r03_refill_bubbles.log).  So when a call reaches the second half of the
+	// current window, the NEXT window is built and uploaded on an internal copy stream; by the time a call needs it the
+	// upload is long complete and the caller's stream only waits for its event (SlotGuard::use).
 	hipError_t ensure(uint64_t lo, uint64_t hi, hipStream_t stream)
 	{
 		// + 80: every wave reads a 64-dword slice starting at the dword of its row's first window
 		const uint64_t wlo = lo >> 5, whi = (hi >> 5) + 80;
+		hipError_t e;
 		if (cur_ >= 0 && wlo >= slot_[cur_].wbase && whi <= slot_[cur_].wbase + slot_[cur_].nwords)
+		{
+			if (next_ < 0 && lookahead_ && whi > slot_[cur_].wbase + slot_[cur_].nwords / 2 && slot_[cur_].nwords >= kMaxRefill)
+			{
+				if (!copy_stream_ && (e = hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking)) != hipSuccess) return e;
+				// from this call's first word on: whatever follows in stream order is inside it
+				if ((e = fill((last_ + 1) % kSlots, wlo, std::max<uint64_t>(refill_, 2 * (whi - wlo)), copy_stream_)) != hipSuccess) return e;
+				next_ = last_;
+				stats_[1]++;
+			}
 			return hipSuccess;
-		const uint32_t reg0 = window(wlo << 5);
+		}
+		if (next_ >= 0 && wlo >= slot_[next_].wbase && whi <= slot_[next_].wbase + slot_[next_].nwords)
+		{
+			// the window prepared ahead becomes the current one
+			if (cur_ >= 0 && (e = slot_[cur_].guard.leave()) != hipSuccess) return e;
+			cur_ = next_;
+			next_ = -1;
+			stats_[2]++;
+			ck_word_ = slot_[cur_].wbase;
+			ck_reg_ = slot_[cur_].host[0];
+			return hipSuccess;
+		}
+		if (next_ >= 0)
+		{   // prepared for a continuation that did not come (a jump in the stream): give the slot back
+			if ((e = slot_[next_].guard.leave()) != hipSuccess) return e;
+			next_ = -1;
+		}
 		const uint64_t n = std::max<uint64_t>(refill_, 2 * (whi - wlo));
 		refill_ = std::min<uint64_t>(refill_ * 4, kMaxRefill);
-		const int nxt = (last_ + 1) % kSlots;
-		Slot& s = slot_[nxt];
+		if (cur_ >= 0 && (e = slot_[cur_].guard.leave()) != hipSuccess) return e;
+		if ((e = fill((last_ + 1) % kSlots, wlo, n, stream)) != hipSuccess) { cur_ = -1; return e; }   // (fill reads the old window: never its own slot)
+		cur_ = last_;
+		stats_[0]++;
+		ck_word_ = wlo;
+		ck_reg_ = slot_[cur_].host[0];
+		return hipSuccess;
+	}
+
+	// {refills in a caller's stream, windows built ahead on the copy stream, switches to a window built ahead, words of the current window}
+	void stats(uint64_t out[4]) const { out[0] = stats_[0]; out[1] = stats_[1]; out[2] = stats_[2]; out[3] = dev_words(); }
+
+	// before every kernel launch on `stream` that reads the current slot
+	hipError_t use(hipStream_t stream) { return cur_ < 0 ? hipSuccess : slot_[cur_].guard.use(stream); }
+
+	uint32_t seed_reg() const { return seed_reg_; }
+	const uint32_t* dev() const { return cur_ < 0 ? nullptr : slot_[cur_].dev; }
+	uint64_t base_bit() const { return cur_ < 0 ? 0 : slot_[cur_].wbase << 5; }
+	uint64_t dev_words() const { return cur_ < 0 ? 0 : slot_[cur_].nwords; }
+
+	void release()
+	{
+		for (Slot& s : slot_)
+		{
+			if (s.host) (void)hipHostFree(s.host);
+			if (s.dev) (void)hipFree(s.dev);
+			s.guard.destroy();
+			s = Slot{};
+		}
+		if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+		copy_stream_ = nullptr;
+		cur_ = next_ = -1;
+	}
+
+private:
+	struct Slot {
+		uint32_t* host = nullptr;
+		uint32_t* dev = nullptr;
+		uint64_t cap = 0, wbase = 0, nwords = 0;
+		SlotGuard guard;
+	};
+
+	// build words [wlo, wlo + n) of the stream in slot `idx` and upload them on `stream`; the slot becomes last_
+	hipError_t fill(int idx, uint64_t wlo, uint64_t n, hipStream_t stream)
+	{
+		const uint32_t reg0 = window(wlo << 5);
+		Slot& s = slot_[idx];
 		hipError_t e;
 		// its upload and every kernel that read it, on any stream, must be done before its pinned source and its device
 		// words are overwritten (SlotGuard); normally long complete
-		if (cur_ >= 0 && (e = slot_[cur_].guard.leave()) != hipSuccess) return e;
 		if ((e = s.guard.wait_free()) != hipSuccess) return e;
 		if (s.cap < n)
 		{
@@ -270,42 +346,20 @@ public:
 		s.wbase = wlo;
 		s.nwords = n;
 		if ((e = hipMemcpyAsync(s.dev, s.host, n * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-		cur_ = last_ = nxt;
-		if ((e = s.guard.uploaded(stream)) != hipSuccess) return e;
-		ck_word_ = wlo;
-		ck_reg_ = reg0;
-		return hipSuccess;
+		last_ = idx;
+		return s.guard.uploaded(stream);
 	}
 
-	// before every kernel launch on `stream` that reads the current slot
-	hipError_t use(hipStream_t stream) { return cur_ < 0 ? hipSuccess : slot_[cur_].guard.use(stream); }
-
-	uint32_t seed_reg() const { return seed_reg_; }
-	const uint32_t* dev() const { return cur_ < 0 ? nullptr : slot_[cur_].dev; }
-	uint64_t base_bit() const { return cur_ < 0 ? 0 : slot_[cur_].wbase << 5; }
-	uint64_t dev_words() const { return cur_ < 0 ? 0 : slot_[cur_].nwords; }
-
-	void release()
-	{
-		for (Slot& s : slot_)
-		{
-			if (s.host) (void)hipHostFree(s.host);
-			if (s.dev) (void)hipFree(s.dev);
-			s.guard.destroy();
-			s = Slot{};
-		}
-		cur_ = -1;
-	}
-
-private:
-	struct Slot {
-		uint32_t* host = nullptr;
-		uint32_t* dev = nullptr;
-		uint64_t cap = 0, wbase = 0, nwords = 0;
-		SlotGuard guard;
-	};
 	Slot slot_[kSlots];
 	int cur_ = -1, last_ = -1;
+	int next_ = -1;                     // a window built ahead on copy_stream_, not yet the current one
+	uint64_t stats_[3] = {0, 0, 0};
+	hipStream_t copy_stream_ = nullptr;
+#ifdef VFGS_NO_LOOKAHEAD            // developer A/B (tools/dev/build_variant.sh): every refill in the caller's stream
+	bool lookahead_ = false;
+#else
+	bool lookahead_ = true;
+#endif
 	uint64_t refill_ = kFirstRefill;
 	uint32_t seed_reg_ = 0xdeadbeefu;   // register at bit 0 (vfgs_hw.c:52-55 power-on value)
 	uint64_t ck_word_ = 0;              // a known (word, register) point to step from
@@ -1936,6 +1990,12 @@ void vfgs_hip_get_params(int out[8])
 	const State& s = S();
 	const int v[8] = {s.scale_shift, s.bs, s.ymin, s.ymax, s.cmin, s.cmax, s.csubx, s.csuby};
 	memcpy(out, v, sizeof v);
+}
+
+void vfgs_hip_get_stream_stats(uint64_t out[4])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().lfsr.stats(out);
 }
 
 int vfgs_hip_last_error(void) { return g_err; }
