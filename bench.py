@@ -225,9 +225,11 @@ def main():
     region = None
     region_launches = max(args.steps, 100)     # (the region's first and last launch run alone: a short region is mostly edges)
     if not args.no_region:
-        for _ in range(2):      # (the first region creates the internal streams and their queues)
+        # (the first region creates the internal streams and their queues; and launches alternating between two queues take a
+        # few dozen launches to reach their steady rate -- 8 warm-up launches: 0.74, 50: 0.76, profiles/r03_ab32_region_warmup.log)
+        for _ in range(2):
             h.overlap_begin(stream)
-            for i in range(4):
+            for i in range(32):
                 step(i)
             h.overlap_end(stream)
         torch.cuda.synchronize()
