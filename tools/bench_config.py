@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--mode", choices=["inplace", "copy", "copy8"], default="inplace",
                     help="inplace (default); copy: out of place, same depth; copy8: 10-bit in, 8-bit out (the CLI's --outdepth 8 fused into the store)")
     ap.add_argument("--overlap", action="store_true", help="time the calls inside one vfgs_hip_overlap_begin/_end region (independent frames, one per call)")
+    ap.add_argument("--region-every", type=int, default=0, help="with --overlap: close and reopen the region every N calls (a join every N calls)")
     ap.add_argument("--streams", type=int, default=1, help="experiment: issue consecutive launches round-robin on this many streams (they may overlap)")
     ap.add_argument("--pool", type=int, default=0, help="buffer sets cycled through (default: enough for > 1.5 GB)")
     ap.add_argument("--single-alloc", action="store_true", help="each set is ONE allocation [Y frames | U frames | V frames] (bench.py's layout)")
@@ -126,6 +127,9 @@ def main():
         h.overlap_begin(st)
     for i in range(args.steps):
         step(i)
+        if args.overlap and args.region_every and (i + 1) % args.region_every == 0 and i + 1 < args.steps:
+            h.overlap_end(st)
+            h.overlap_begin(st)
     if args.overlap:
         h.overlap_end(st)
     host_us = (time.perf_counter() - th0) / args.steps * 1e6     # what the calling thread spends per call (it never waits here)
