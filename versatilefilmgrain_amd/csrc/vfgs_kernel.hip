@@ -829,7 +829,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 //     units are stored one step later, once lane 0 of the next segment has delivered the last dwords of its lane 63;
 //   * row bases and segment offsets live in the buffer descriptor (base, num_records = bytes of the row left), so the
 //     hardware range check covers every access of every lane: lanes behind the row's end load 0 and store nothing.
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE, int NEG>
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE, int NEG, int NARROW>
 __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, const int r,
                                              const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
 {
@@ -916,18 +916,31 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	// group that does not exist -- and no access of any lane can leave the row.  (Measured on gfx950: a scalar offset
 	// operand IS part of what is checked against num_records, so the row offset has to go into the base.)
 	const int tsegs = pd.rw_segs;
-	const int ngroups = (tsegs + 3) >> 2;
+	constexpr int NU = 4;                          // positions per group = register sets of the ring
+	const int ngroups = (tsegs + NU - 1) / NU;
 	const uint8_t* sbase = a.src[comp] + (uint64_t)f * pd.fpitch;
 	uint8_t* dbase = a.dst[comp] + (uint64_t)f * pd.dfpitch;
 	const uint32_t lane16 = (uint32_t)lane * 16;
-	constexpr uint32_t GB = 4 * kMaxUnits * 16;          // bytes of a group
+	constexpr uint32_t GB = NU * kMaxUnits * 16;         // bytes of a group
 	auto row_off = [&](int k) { return (uint32_t)((base + RSTR * k - prow0) * (int)pd.pitch); };
 	auto left = [&](int g) { const uint32_t o = (uint32_t)g * GB; return o < pd.rowbytes ? min(pd.rowbytes - o, GB) : 0u; };
-	uint32_t w[4][4];
+	uint32_t w[NU][4];
+	if constexpr (NARROW == 0)
 	{
 		const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(sbase + (k0 < k1 ? row_off(k0) : 0u), k0 < k1 ? left(0) : 0u);
 #pragma unroll
-		for (int u = 0; u < 4; u++) load_seg<LDA>(rs0, lane16 + u * (kMaxUnits * 16), 0, w[u]);
+		for (int u = 0; u < NU; u++) load_seg<LDA>(rs0, lane16 + u * (kMaxUnits * 16), 0, w[u]);
+	}
+	else
+	{
+		// rows of NARROW positions: the four register sets hold 4 / NARROW consecutive rows of the wave
+#pragma unroll
+		for (int u = 0; u < NU; u++)
+		{
+			const int k = k0 + u / NARROW;
+			const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(sbase + (k < k1 ? row_off(k) : 0u), k < k1 ? pd.rowbytes : 0u);
+			load_seg<LDA>(rs0, lane16 + (u % NARROW) * (kMaxUnits * 16), 0, w[u]);
+		}
 	}
 #if VFGS_RW_ABLATE < 2
 #pragma unroll
@@ -942,6 +955,10 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 #pragma unroll
 	for (int i = 0; i < NPE; i++)
 	{
+		// (rows of up to 252 blocks -- 2160p and narrower -- need the first round only, 4320p two of the three: a wave-uniform
+		// branch around arithmetic and LDS writes; the LFSR loads above stay unconditional, switched off by their offsets, so
+		// that the waits below can still be counted)
+		if (i > 0 && i * kWavesPerWG * 64 >= a.nblk + 4) break;
 		const int e = (int)threadIdx.x + i * kWavesPerWG * 64;
 		const uint32_t blk = (uint32_t)min(max(e - 1, 0), last);
 		bool neg;
@@ -985,6 +1002,87 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	uint32_t outp[4] = {0, 0, 0, 0};       // the previous segment's units: dwords K.. of its lanes (the first 4 - K dwords of a unit)
 	uint32_t tp[4] = {0, 0, 0, 0};         // ... and the first K dwords its lanes computed: they belong one lane down
 	__amdgpu_buffer_rsrc_t pdst = make_rsrc(dbase, 0);     // where the previous GROUP's last segment goes
+	if constexpr (NARROW != 0)
+	{
+		// Rows of one or two positions (chroma of 1080p 4:2:0 at 10 bit, of 2160p at 8 bit: 2 KiB and less).  Walked row by
+		// row, half of the ring would stay empty and a wave would keep 2 KiB in flight where the chip needs 4: so a group is
+		// 4 / NARROW consecutive rows of the wave.  Position q of the wave's sequence = row k0 + q / NARROW, position
+		// q % NARROW of it; everything that depends on the row is wave-uniform data of the slot; the overlap lines are a
+		// wave-uniform branch per slot (not two walks: a group may hold one of each kind).
+		constexpr int P = NARROW, RPG = NU / P;
+		const int ngr = (k1 - k0 + RPG - 1) / RPG;
+		for (int G = 0; G < ngr; G++)
+		{
+			const int kg = k0 + G * RPG;
+#pragma unroll
+			for (int u = 0; u < NU; u++)
+			{
+				const int p = u % P;                                   // position inside the row (compile time after unrolling)
+				const int k = kg + u / P;                              // the slot's row
+				const bool valid = k < k1, nvalid = k + RPG < k1;      // wave-uniform
+				const __amdgpu_buffer_rsrc_t nsrc = make_rsrc(sbase + (nvalid ? row_off(k + RPG) : 0u), nvalid ? pd.rowbytes : 0u);
+				const __amdgpu_buffer_rsrc_t cdst = make_rsrc(dbase + (valid ? row_off(k) : 0u), valid ? pd.rowbytes : 0u);
+				uint32_t t[4];
+#pragma unroll
+				for (int d = 0; d < K; d++) t[d] = lane_up(p == 0 ? 0u : carry[d], w[u][4 - K + d]);
+#pragma unroll
+				for (int d = 0; d < K; d++) carry[d] = rot_up(w[u][4 - K + d]);
+#pragma unroll
+				for (int d = K; d < 4; d++) asm volatile("v_mov_b32 %0, %1" : "=v"(t[d]) : "v"(w[u][d - K]));
+				load_seg<LDA>(nsrc, lane16 + p * (kMaxUnits * 16), 0, w[u]);
+				if (valid)
+				{
+					const int j = base + RSTR * k - Rabs * RPB;        // row inside the block row
+					const int jrow = j * SUBY;
+					const uint32_t rowoff = (uint32_t)j * RS, uprowoff = (uint32_t)(RPB + j) * RS;
+					const int wc_ = jrow == 0 ? (SUBY > 1 ? 20 : 12) : 24, wu_ = jrow == 0 ? (SUBY > 1 ? 20 : 24) : 12;
+					const uint8_t* pe = lds + idx0;
+					bool edge_on[NEF];
+					if (M::PAIR)
+					{
+						const int jl = cl + p * SSTEP;
+						edge_on[0] = jl >= 0 && jl + 1 < 2 * a.nblk;
+					}
+					else
+					{
+#pragma unroll
+						for (int ed = 0; ed < M::NE; ed++) edge_on[ed] = (cl + p * SSTEP + ed >= 0) && (cl + p * SSTEP + ed < last);
+					}
+					RunParam<NR> rp, up;
+#pragma unroll
+					for (int rr = 0; rr < NR; rr++) rp.pa[rr] = *(const uint32_t*)(pe + PT_CUR + (p * BPS + rr) * 4) + pairoff;
+					if (Rabs > 0 && jrow <= 1)     // blends in the block above (vfgs_hw.c:173-188, 223-229)
+					{
+#pragma unroll
+						for (int rr = 0; rr < NR; rr++) up.pa[rr] = *(const uint32_t*)(pe + PT_UP + (p * BPS + rr) * 4) + pairoff;
+						grain_unit<DEPTH, BW, true, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, wc_, wu_, edge_on, first, lo2, hi2);
+					}
+					else
+					{
+#pragma unroll
+						for (int rr = 0; rr < NR; rr++) up.pa[rr] = 0u;
+						grain_unit<DEPTH, BW, false, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, 0, 0, edge_on, first, lo2, hi2);
+					}
+				}
+				// the previous position (of this row, or the last one of the row before: `pdst` is its row) is complete
+#pragma unroll
+				for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(rot_down(t[d]), tp[d]);
+				store_b128<STA>(pdst, lane16 + ((p + P - 1) % P) * (kMaxUnits * 16), 0, outp);
+				pdst = cdst;
+#pragma unroll
+				for (int d = K; d < 4; d++) outp[d - K] = t[d];
+#pragma unroll
+				for (int d = 0; d < K; d++) tp[d] = t[d];
+#if VFGS_SCHED_FENCE
+				__builtin_amdgcn_sched_barrier(0);
+#endif
+			}
+		}
+#pragma unroll
+		for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(0u, tp[d]);
+		store_b128<STA>(pdst, lane16 + (P - 1) * (kMaxUnits * 16), 0, outp);
+		return;
+	}
 	// one row; `overlap` is a type so that the walk of the (rare) overlap lines is code of its own: the hot loop carries
 	// neither their arithmetic nor a branch around it
 	auto walk_row = [&](auto overlap, const int k) {
@@ -1003,10 +1101,10 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 			const uint32_t nso = nvalid ? (lastg ? row_off(k + 1) : ro) + (uint32_t)ng * GB : 0u;
 			const __amdgpu_buffer_rsrc_t nsrc = make_rsrc(sbase + nso, nvalid ? left(ng) : 0u);
 			const __amdgpu_buffer_rsrc_t cdst = make_rsrc(dbase + (ro + (uint32_t)g * GB), left(g));
-			const uint8_t* pe = lds + idx0 + (uint32_t)(g * 4 * BPS * 4);
-			const int clg = cl + g * 4 * SSTEP;
+			const uint8_t* pe = lds + idx0 + (uint32_t)(g * NU * BPS * 4);
+			const int clg = cl + g * NU * SSTEP;
 #pragma unroll
-			for (int u = 0; u < 4; u++)
+			for (int u = 0; u < NU; u++)
 			{
 				const bool firsts = u == 0 && g == 0;                    // first segment of the row
 				// assemble my 16 bytes: the last K dwords of the unit of the lane before me, the first 4 - K of mine
@@ -1024,7 +1122,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 #if VFGS_RW_ABLATE >= 1       // timing experiments only (tools/dev/build_variant.sh): copy, WRONG output
 				if (false)
 #else
-				if (4 * g + u < tsegs)
+				if (NU * g + u < tsegs)
 #endif
 				{
 					bool edge_on[NEF];
@@ -1050,7 +1148,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 				// its lane 63 lies behind that row's end and is never stored)
 #pragma unroll
 				for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(rot_down(t[d]), tp[d]);
-				if (u == 0) store_b128<STA>(pdst, lane16 + 3 * (kMaxUnits * 16), 0, outp);
+				if (u == 0) store_b128<STA>(pdst, lane16 + (NU - 1) * (kMaxUnits * 16), 0, outp);
 				else store_b128<STA>(cdst, lane16 + (u - 1) * (kMaxUnits * 16), 0, outp);
 #pragma unroll
 				for (int d = K; d < 4; d++) outp[d - K] = t[d];
@@ -1072,7 +1170,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	// the last segment of my last row
 #pragma unroll
 	for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(0u, tp[d]);
-	store_b128<STA>(pdst, lane16 + 3 * (kMaxUnits * 16), 0, outp);
+	store_b128<STA>(pdst, lane16 + (NU - 1) * (kMaxUnits * 16), 0, outp);
 }
 
 // 8-bit planes with 8-sample blocks hold three block runs and two edges per lane (LaneMap): those kernels get the
@@ -1127,13 +1225,19 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 	int r = (int)(blockIdx.x >> a.lfronts);
 	if (f >= a.nframes) return;
 	if (r < a.pd[0].wgs)
-		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
 		const int comp = 1 + (r >= a.pd[1].wgs);
 		if (comp == 2) r -= a.pd[1].wgs;
-		run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+		// horizontally subsampled chroma rows of one or two positions (2 KiB and less: 1080p at 10 bit, 2160p at 8 bit): several rows per group
+		if (CSUBX == 2 && a.pd[1].rw_segs == 2)
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 2>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+		else if (CSUBX == 2 && a.pd[1].rw_segs == 1)
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 1>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+		else
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 0>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 	}
 }
 
