@@ -3,9 +3,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_driver_args.json 2> gpurun_out/bench_default.err; cat gpurun_out/bench_driver_args.json
-python bench.py > gpurun_out/bench_default.json 2>> gpurun_out/bench_default.err; cat gpurun_out/bench_default.json
-python bench.py --batch 1 --steps 1000 --warmup 300 --pool 24 --no-cpu > gpurun_out/bench_b1.json 2>> gpurun_out/bench_default.err; cat gpurun_out/bench_b1.json
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --no-region > $GRAFT_REPO_ROOT/gpurun_out/prof_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --no-region --preroll-ms 20 --steps 8 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_fetch.log 2>&1
@@ -38,5 +35,11 @@ if 'FETCH_SIZE' in pm and 'WRITE_SIZE' in pm:
                           'date': datetime.date.today().isoformat(),
                           'correction': 'FETCH_SIZE x2 (gfx950, 16 B/lane streaming reads), WRITE_SIZE x1; KiB units'}
 json.dump(out, open('gpurun_out/profile_summary.json','w'), indent=1)
+if 'hbm_traffic' in out:
+    json.dump(out['hbm_traffic'], open('profiles/hbm_traffic.json','w'), indent=1)     # (the box's copy: the bench lines below then carry the traffic of THIS source)
 print(json.dumps(out, indent=1))
 PY
+# the bench lines last: they read profiles/hbm_traffic.json written above (same kernel source, same box)
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_driver_args.json 2> gpurun_out/bench_default.err; cat gpurun_out/bench_driver_args.json
+python bench.py > gpurun_out/bench_default.json 2>> gpurun_out/bench_default.err; cat gpurun_out/bench_default.json
+python bench.py --batch 1 --steps 1000 --warmup 300 --pool 24 --no-cpu > gpurun_out/bench_b1.json 2>> gpurun_out/bench_default.err; cat gpurun_out/bench_b1.json
