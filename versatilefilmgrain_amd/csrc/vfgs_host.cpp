@@ -782,14 +782,14 @@ int check_luts(State& s)
 	return 0;
 }
 
-// want_general: the caller needs the general (slot-interleaved) form even where one pattern would do (fused 8-bit output)
-int upload_tables(State& s, hipStream_t stream, bool want_general)
+// Which form of the table image (vfgs_layout.h) the current state gets.  want_general: the caller needs the general
+// (slot-interleaved) form even where one pattern would do (fused 8-bit output).  The pattern LUTs must have been digested.
+void image_form(const State& s, bool want_general, bool* one_y, bool* one_c)
 {
-	if (int e = check_luts(s)) return e;
-	const int slot[3] = {s.plut_slot[0], s.plut_slot[1], s.plut_slot[2]};     // (check_luts has just digested them)
 #ifdef VFGS_NO_ONE_PATTERN      // tools/gpu_variants.sh: always the general form
 	want_general = true;
 #endif
+	const int slot[3] = {s.plut_slot[0], s.plut_slot[1], s.plut_slot[2]};
 	// (the one-pattern form stores a negated copy of the pattern, vfgs_layout.h: not for a pattern that holds -128.  Slots the
 	// firmware generated on the device are clipped to +-127; slot 8 is the all-zero pattern)
 	auto negatable = [&](int pt, int k) {
@@ -799,8 +799,16 @@ int upload_tables(State& s, hipStream_t stream, bool want_general)
 			if (memchr(s.bank[pt][k][r], 0x80, cols)) return false;
 		return true;
 	};
-	const bool one_y = !want_general && slot[0] >= 0 && negatable(0, slot[0]);
-	const bool one_c = !want_general && slot[1] >= 0 && slot[2] >= 0 && negatable(1, slot[1]) && negatable(1, slot[2]);
+	*one_y = !want_general && slot[0] >= 0 && negatable(0, slot[0]);
+	*one_c = !want_general && slot[1] >= 0 && slot[2] >= 0 && negatable(1, slot[1]) && negatable(1, slot[2]);
+}
+
+int upload_tables(State& s, hipStream_t stream, bool want_general)
+{
+	if (int e = check_luts(s)) return e;
+	const int slot[3] = {s.plut_slot[0], s.plut_slot[1], s.plut_slot[2]};     // (check_luts has just digested them)
+	bool one_y, one_c;
+	image_form(s, want_general, &one_y, &one_c);
 	if (!s.tables_dirty && s.tables_ring.current() && one_y == s.img_one_y && one_c == s.img_one_c)
 		return 0;
 	if (int e = fw_flush(s, stream)) return e;
@@ -932,6 +940,10 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	const bool aligned = vfgs::aligned_ok(8 + s.bs, (int)s.csubx, (int)nblk, dg.out8);
 	const bool rowwalk = vfgs::rowwalk_ok(8 + s.bs, (int)s.csubx, (int)nblk, dg.out8);
 	int rw_shrink = 0;                      // row walk: halvings of the rows per wave (small launches)
+	bool form_one_y = false, form_one_c = false;   // the form the table image will have (upload_tables below)
+	digest_pluts(s);
+	if (s.plut_bad_c < 0) image_form(s, dg.out8, &form_one_y, &form_one_c);
+	(void)form_one_c;
 	for (int pass = 0; pass < 3; pass++)
 	{
 		long waves = 0;
@@ -959,7 +971,10 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 				const int units = (int)(d.rowbytes / 16);
 				d.rw_segs = (units + 1 + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
 				int rpw = 1;
-				while (vfgs::kWavesPerWG * rpw * 2 <= (int)rpb && (size_t)vfgs::kWavesPerWG * rpw * d.rowbytes < VFGS_RW_WG_BYTES) rpw *= 2;
+				// (8-bit luma in the general form -- per-sample pattern selection, 24 LDS instructions per position -- does better with
+				// waves of one row: +4 % at 2160p, profiles/r03_ab39_workgroup_bytes_8bit.log; every other form loses 4-7 % with them)
+				const size_t wg_bytes = (pt == 0 && s.bs == 0 && !form_one_y) ? VFGS_RW_WG_BYTES / 2 : VFGS_RW_WG_BYTES;
+				while (vfgs::kWavesPerWG * rpw * 2 <= (int)rpb && (size_t)vfgs::kWavesPerWG * rpw * d.rowbytes < wg_bytes) rpw *= 2;
 				for (int i = 0; i < rw_shrink && rpw > 1; i++) rpw /= 2;
 				d.rw_rpw = rpw;
 				d.rw_splits = std::max<int>(1, (int)rpb / (vfgs::kWavesPerWG * rpw));
