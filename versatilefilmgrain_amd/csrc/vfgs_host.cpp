@@ -43,8 +43,11 @@ __asm__(".section .rodata\n.balign 16\n.hidden vfgs_fw_blob\n.globl vfgs_fw_blob
 extern "C" const unsigned char vfgs_fw_blob[], vfgs_fw_blob_end[];
 
 #ifndef VFGS_MIN_FILL_PCT
-#define VFGS_MIN_FILL_PCT 25   // a launch should fill at least this share of the chip's wave slots (else: fewer rows per wave)
+#define VFGS_MIN_FILL_PCT 25   // tiled kernels: a launch should fill at least this share of the chip's wave slots (else: fewer rows per wave)
 #endif
+#ifndef VFGS_RW_MIN_FILL_PCT
+#define VFGS_RW_MIN_FILL_PCT 100  // row walk: ... of the wave slots (25 -> 100: single frames +2..8 %, 8-frame launches unchanged; 300 loses 10 % at
+#endif                            // 1080p x 8: profiles/r03_ab40_min_fill.log)
 #ifndef VFGS_RW_WG_BYTES
 #define VFGS_RW_WG_BYTES 24576 // row walk: a workgroup's rows should hold at least this many bytes (where its block row allows)
 #endif
@@ -1006,7 +1009,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		if (rowwalk)
 		{
 			// a launch that leaves most wave slots empty gets more, shorter workgroups
-			if (pass < 2 && waves * 100 < VFGS_MIN_FILL_PCT * slots && (a.pd[0].rw_rpw > 1 || a.pd[1].rw_rpw > 1)) { rw_shrink++; continue; }
+			if (pass < 2 && waves * 100 < VFGS_RW_MIN_FILL_PCT * slots && (a.pd[0].rw_rpw > 1 || a.pd[1].rw_rpw > 1)) { rw_shrink++; continue; }
 			break;
 		}
 		if (pass == 0)

@@ -78,7 +78,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #if VFGS_WAVES != 4 || VFGS_ROWS_PER_WAVE != 4 || VFGS_WG_PER_CU != 4 || VFGS_WG_PER_CU_8BIT_SUB != 3 || VFGS_LDAUX != 0 || VFGS_STAUX != 0 || \
     VFGS_PREFETCH != 1 || VFGS_SCHED_FENCE != 1 || VFGS_SPLIT_INTERLEAVE != 0 || VFGS_ABLATE != 0 || VFGS_ALIGNED != 1 || VFGS_LANE_SHIFT_DPP != 1 || \
     VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || VFGS_RW_ABLATE != 0 || VFGS_XABLATE != 0 || defined(VFGS_NO_ROWWALK) || defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || \
-    defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_ALIGN_TEST) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_MIN_FILL_PCT)
+    defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_ALIGN_TEST) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_MIN_FILL_PCT) || defined(VFGS_RW_MIN_FILL_PCT)
 #error "libvfgs_hip: a tuning / ablation knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
 #endif
