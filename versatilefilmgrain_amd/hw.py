@@ -20,6 +20,31 @@ class VfgsHipError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's) and opens it by path:
+    if this library is loaded first it binds /opt/rocm's copy, a later `import torch` brings a second runtime into the process
+    and whichever initialises second finds no device ("no ROCm-capable device is detected", seen when build() and smoke() ran in
+    one process).  So where torch is installed but not imported yet, its copy is opened first (by the path torch itself will
+    use) and libvfgs_hip.so's NEEDED entry resolves to it -- the arrangement every test and bench.py run has anyway (they import
+    torch first).  Without torch (a C host) nothing happens and /opt/rocm's runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    rt = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if rt.exists():
+        try:
+            C.CDLL(str(rt), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load(path: Path | None = None) -> C.CDLL:
     """dlopen libvfgs_hip.so; raises (never falls back) when it has not been built."""
     global _lib
@@ -29,6 +54,7 @@ def load(path: Path | None = None) -> C.CDLL:
     if not path.exists():
         raise VfgsHipError(f"{path} not built: run `python -m versatilefilmgrain_amd.build` "
                            "(needs hipcc); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(str(path))
     vp, u, i = C.c_void_p, C.c_uint, C.c_int
     lib.vfgs_set_luma_pattern.argtypes = [i, vp]
