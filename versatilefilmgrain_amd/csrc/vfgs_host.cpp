@@ -234,19 +234,8 @@ public:
 		// + 80: every wave reads a 64-dword slice starting at the dword of its row's first window
 		const uint64_t wlo = lo >> 5, whi = (hi >> 5) + 80;
 		hipError_t e;
-		if (cur_ >= 0 && wlo >= slot_[cur_].wbase && whi <= slot_[cur_].wbase + slot_[cur_].nwords)
-		{
-			if (next_ < 0 && lookahead_ && whi > slot_[cur_].wbase + slot_[cur_].nwords / 2 && slot_[cur_].nwords >= kMaxRefill)
-			{
-				if (!copy_stream_ && (e = hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking)) != hipSuccess) return e;
-				// from this call's first word on: whatever follows in stream order is inside it
-				if ((e = fill((last_ + 1) % kSlots, wlo, std::max<uint64_t>(refill_, 2 * (whi - wlo)), copy_stream_)) != hipSuccess) return e;
-				next_ = last_;
-				stats_[1]++;
-			}
-			return hipSuccess;
-		}
-		if (next_ >= 0 && wlo >= slot_[next_].wbase && whi <= slot_[next_].wbase + slot_[next_].nwords)
+		if (!(cur_ >= 0 && wlo >= slot_[cur_].wbase && whi <= slot_[cur_].wbase + slot_[cur_].nwords) &&
+		    next_ >= 0 && wlo >= slot_[next_].wbase && whi <= slot_[next_].wbase + slot_[next_].nwords)
 		{
 			// the window prepared ahead becomes the current one
 			if (cur_ >= 0 && (e = slot_[cur_].guard.leave()) != hipSuccess) return e;
@@ -255,6 +244,19 @@ public:
 			stats_[2]++;
 			ck_word_ = slot_[cur_].wbase;
 			ck_reg_ = slot_[cur_].host[0];
+		}
+		if (cur_ >= 0 && wlo >= slot_[cur_].wbase && whi <= slot_[cur_].wbase + slot_[cur_].nwords)
+		{
+			// (also right after a switch: a launch that uses up more than half a window -- 64 frames of 4320p at 8 ranks -- needs
+			// the next one built during every call)
+			if (next_ < 0 && lookahead_ && whi > slot_[cur_].wbase + slot_[cur_].nwords / 2 && slot_[cur_].nwords >= kMaxRefill)
+			{
+				if (!copy_stream_ && (e = hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking)) != hipSuccess) return e;
+				// from this call's first word on: whatever follows in stream order is inside it
+				if ((e = fill((last_ + 1) % kSlots, wlo, std::max<uint64_t>(refill_, 2 * (whi - wlo)), copy_stream_)) != hipSuccess) return e;
+				next_ = last_;
+				stats_[1]++;
+			}
 			return hipSuccess;
 		}
 		if (next_ >= 0)
