@@ -54,8 +54,7 @@ def device_pitches(f):
 @pytest.mark.parametrize("width", WIDTHS)
 def test_row_ends_on_and_around_position_and_group_boundaries(hip, name, width):
     ora, (depth, sx, sy) = program(hip, name)
-    if depth == 8 and sx == 2 and ((width + 15) // 16) % 2:
-        pytest.skip("odd block count at 8-bit 4:2:x: rows are not whole units, tiled kernels (covered elsewhere)")
+    # (8-bit 4:2:x with an odd block count: chroma rows end in half a 16-byte unit, cut by the buffer range check per dword)
     for i, height in enumerate(HEIGHTS):
         f = garbage_frame(width, height, depth, sx, sy, width * 7 + i)
         want = f.copy()
@@ -148,3 +147,37 @@ def test_batches_with_frame_pitch_and_out_of_place(hip, name):
     check(dY, dU, dV, cols=(W + 15) // 16 * 16)
     assert not dY.view(torch.int16 if depth > 8 else torch.uint8).reshape(N, -1)[:, :f0.Y.size].reshape(N, -1, f0.stride)[:, :H, (W + 15) // 16 * 16:].any()   # ... and stays untouched
     assert hip.seed_state() == st
+
+
+@pytest.mark.parametrize("name", ["fgs_afgs1_test1_8_420", "fgs_sei_8_420", "fgs_sei_ff_test6_8_422"])
+@pytest.mark.parametrize("width", [144, 720, 3856, 8176])
+def test_odd_block_counts_at_8_bit_420_and_422(hip, name, width):
+    """8-bit 4:2:x rows of an odd number of blocks (SD video: 720 = 45 blocks) end in HALF a 16-byte unit.  The row walk leaves
+    that to the raw-buffer range check (a row's descriptor holds exactly the row's bytes; checked per dword): the samples and
+    the garbage in the stride padding behind them must come out as the reference leaves them (whole blocks).
+    8176 = 511 blocks: the widest odd row the parameter table holds."""
+    ora, (depth, sx, sy) = program(hip, name)
+    assert ((width + 15) // 16) % 2 == 1
+    for i, height in enumerate([16, 33, 70] if width < 4000 else [33]):
+        f = garbage_frame(width, height, depth, sx, sy, width + i)
+        want = f.copy()
+        ora.add_grain_frame(want)
+        d = DevFrame(f)
+        hip.add_grain_frame_dev(*d.ptrs(), f.width, f.height, f.stride, f.cstride, stream_ptr())
+        assert d.download().equal_all(want), (name, width, height)
+        assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name", ["fgs_afgs1_test1_8_420", "fgs_sei_8_420"])
+def test_rows_wider_than_the_parameter_table_with_odd_block_count(hip, name):
+    """513 blocks (8208 samples) at 8-bit 4:2:0: one block more than the row walk's parameter table holds AND rows that are not whole
+    units -- the tiled kernels with shifted accesses (vfgs_kernel.hip has_shifted), the only launches that still use them besides the
+    fused 8-bit output."""
+    ora, (depth, sx, sy) = program(hip, name)
+    f = garbage_frame(8208, 33, depth, sx, sy, 4)
+    want = f.copy()
+    ora.add_grain_frame(want)
+    d = DevFrame(f)
+    hip.add_grain_frame_dev(*d.ptrs(), f.width, f.height, f.stride, f.cstride, stream_ptr())
+    assert d.download().equal_all(want)
+    assert hip.seed_state() == ora.seed_state()

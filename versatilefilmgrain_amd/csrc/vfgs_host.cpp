@@ -986,7 +986,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 			{
 				// a wave streams whole rows: positions = the row's units + the one behind them (the lanes compute bytes shifted
 				// by part of a unit); a workgroup = kWavesPerWG x rw_rpw rows of one block row, about 60 KB where the block row allows
-				const int units = (int)(d.rowbytes / 16);
+				const int units = (int)((d.rowbytes + 15) / 16);       // (8-bit 4:2:x rows of an odd number of blocks end in half a unit)
 				d.rw_segs = (units + 1 + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
 				int rpw = 1;
 				// (8-bit luma in the general form -- per-sample pattern selection, 24 LDS instructions per position -- does better with
