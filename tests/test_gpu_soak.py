@@ -210,3 +210,37 @@ def test_lfsr_window_lookahead_across_refills():
     assert h.seed_state() == ora.seed_state()
     stats = h.stream_stats()
     assert stats["windows_built_ahead"] >= 1 and stats["switches_to_built_ahead"] >= 1, stats
+
+
+def test_overlap_region_mixed_with_host_memory_calls():
+    """Inside a region the drop-in host-memory calls (vfgs_add_grain_stripe: complete on return, on the library's own stream) may
+    be mixed with the device-pointer calls: frames are independent, the seed registers advance in CALL order whatever stream a
+    frame runs on."""
+    import torch
+    from gpu_util import DevFrame
+    from versatilefilmgrain_amd import hw
+
+    h = hw.VfgsHip(device=0)
+    rec = T.load_trace("fgs_sei_10_420")
+    T.replay(h, rec)
+    ora = T.OracleHW()
+    T.replay(ora, rec)
+    frames, _ = T.lcg_frames(1936, 272, 10, 2, 2, 9)
+    want = [f.copy() for f in frames]
+    devs = {i: DevFrame(f) for i, f in enumerate(frames) if i % 3 != 1}
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    h.overlap_begin(st)
+    for i, f in enumerate(frames):
+        if i % 3 == 1:      # a host-memory frame in between
+            h.add_grain_stripe(f.Y.ctypes.data, f.U.ctypes.data, f.V.ctypes.data, 0, f.width, f.height, f.stride, f.cstride)
+        else:
+            d = devs[i]
+            h.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), f.width, f.height, f.stride, f.cstride, st)
+        ora.add_grain_frame(want[i])
+    h.overlap_end(st)
+    torch.cuda.synchronize()
+    for i, f in enumerate(frames):
+        got = f if i % 3 == 1 else devs[i].download()
+        assert got.equal_all(want[i]), i
+    assert h.seed_state() == ora.seed_state()
