@@ -761,7 +761,7 @@ void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool
 			// the kernel reads the result's high half instead of shifting; <= 255 << 10 fits the 24-bit field
 			const int sc = s.slut[c][i] << (16 - s.scale_shift);
 			lut[i] = (sel << 24) | ((uint32_t)sc & 0xffffffu);             // +scale table
-			lut[256 + i] = (sel << 24) | ((uint32_t)(-sc) & 0xffffffu);    // -scale table
+			if (!(c == 0 ? one_y : one_c)) lut[256 + i] = (sel << 24) | ((uint32_t)(-sc) & 0xffffffu);    // -scale table (general form only)
 		}
 	}
 }

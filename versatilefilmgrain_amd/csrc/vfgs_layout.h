@@ -97,7 +97,7 @@ constexpr int kParamBytes = 2 * kParamTableBytes;
 // Device image of everything the kernel looks up: one sub-image per plane type (luma; chroma) -- or per chroma
 // component -- and a workgroup (which works on ONE plane) copies the sub-image of its plane to LDS offset 0.
 //
-//   luma image  : [LUT Y : 2 x 256 dwords] [luma bank]
+//   luma image  : [LUT Y : 2 x 256 dwords] [luma bank]          (one-pattern form: 1 x 256 dwords, the +scale table, then the bank and its negated copy)
 //   chroma image: [LUT Cb: 2 x 256 dwords] [LUT Cr: 2 x 256 dwords] [chroma bank]                 (general form)
 //             or: [LUT Cb] [bank of Cb's pattern]   and   [LUT Cr] [bank of Cr's pattern]          (one-pattern form)
 //
@@ -144,8 +144,9 @@ constexpr ImageLayout image_layout(int csubx, int csuby, bool one_y, bool one_c)
 	L.ch = 64 / csuby;
 	L.y_rs = one_y ? 64 + 16 : 64 * kSlots + 16;
 	L.c_rs = one_c ? L.cw + 16 : L.cw * kSlots + 16;
-	L.y_bank = L.lut_bytes;
-	L.c_bank = one_c ? L.lut_bytes : 2 * L.lut_bytes;
+	// (the one-pattern form never reads the -scale table: its sign is a choice of bank; only the +scale half is stored)
+	L.y_bank = one_y ? L.lut_bytes / 2 : L.lut_bytes;
+	L.c_bank = one_c ? L.lut_bytes / 2 : 2 * L.lut_bytes;
 	L.y_neg = one_y ? 64 * L.y_rs : 0;
 	L.c_neg = one_c ? L.ch * L.c_rs : 0;
 	L.y_bytes = L.y_bank + 64 * L.y_rs + L.y_neg;
