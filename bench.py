@@ -24,6 +24,11 @@ frames' worth at every N ("weak").  At N=1 a step is `batch` whole frames in one
             launch, in place) runs on freshly generated frames from a reset seed state, and every frame of it is compared
             with the oracle on the host (each rank its own stripes); true only if every byte and the seed registers agree.
 
+`configs` (N=1 only) = BASELINE.json configs[0..3] -- 1080p fgs_sei / ff_test1, 2160p ar_test1, 2160p 8-bit 4:4:4 AFGS1 -- each at the
+            stated frames per launch: launch duration (HIP events, plain stream), fraction of the 8 TB/s peak, the kernel the
+            library reports having dispatched (vfgs_hip_last_launch_info), and a parity check of that shape against the oracle.
+A parity failure anywhere withholds the numbers: the line then carries `error` instead of `value`, and the exit code is 1.
+
 `--gpus N` without a launcher around it (WORLD_SIZE unset): this process starts `python -m torch.distributed.run` with N
 ranks as a CHILD process -- before anything touches the GPU -- and relays its output and exit code.
 `--scaling weak` (default): a step = N x batch frames, per-GPU work constant in N.  `--scaling strong`: a step = batch
@@ -97,9 +102,107 @@ def cpu_baseline(seconds=10.0):
             "host_cpus": os.cpu_count()}
 
 
+# everything that shapes the grain kernels' code object AND the launches the host makes of them: a profile (rocprof kernel
+# stats, PMC traffic) is only quoted for the sources it was taken with
+PROFILED_SOURCES = ("vfgs_kernel.hip", "vfgs_layout.h", "vfgs_host.cpp")
+
+
 def kernel_sha():
     import hashlib
-    return hashlib.sha256((ROOT / "versatilefilmgrain_amd" / "csrc" / "vfgs_kernel.hip").read_bytes()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for name in PROFILED_SOURCES:
+        h.update(name.encode() + b"\0" + (ROOT / "versatilefilmgrain_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+# BASELINE.json configs[0..3] (configs[4] is the headline workload above): name, w, h, depth, (subx, suby), trace, frames per launch.
+# Every configuration is reported at 8 frames per launch (the headline's batch) and at a batch of about 400 MB -- a launch pays
+# ~5 us of fill, drain and kernel boundary, which is a quarter of a 100 MB launch.
+CONFIGS = [
+    ("1920x1080 10-bit 4:2:0, cfg fgs_sei", 1920, 1080, 10, (2, 2), "fgs_sei_10_420", (8, 32)),
+    ("1920x1080 10-bit 4:2:0, cfg fgs_sei_ff_test1", 1920, 1080, 10, (2, 2), "fgs_sei_ff_test1_10_420", (8, 32)),
+    ("3840x2160 10-bit 4:2:0, cfg fgs_sei_ar_test1", 3840, 2160, 10, (2, 2), "fgs_sei_ar_test1_10_420", (8,)),
+    ("3840x2160 8-bit 4:4:4, cfg fgs_afgs1_test1", 3840, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", (8,)),
+]
+
+
+def bench_configs(h, stream, steps_ms=60.0):
+    """BASELINE.json configs[0..3] on this GPU: device-resident frames, in place, plain stream, HIP events on the launching
+    stream; one post-timing launch of the timed shape per entry is compared with the oracle, frame by frame."""
+    import numpy as np
+    import torch
+    import vfgs_testlib as T
+    out = []
+    for name, w, hh, depth, (sx, sy), trace, batches in CONFIGS:
+        rec = T.load_trace(trace)
+        dt = torch.int16 if depth > 8 else torch.uint8
+        npdt = np.uint16 if depth > 8 else np.uint8
+        sz = 2 if depth > 8 else 1
+        cw, ch = w // sx, hh // sy
+        ny, nc = hh * w, ch * cw
+        frame_bytes = sz * (ny + 2 * nc)
+        for batch in batches:
+            h.lib.vfgs_hip_reset_state()
+            T.replay(h, rec)
+            pool = max(3, int(1.0e9 // (frame_bytes * batch)) + 1)       # > 1 GB cycled through: nothing is served by the 256 MiB Infinity Cache
+            g = torch.Generator(device="cuda").manual_seed(11)
+            sets = [torch.randint(0, 1 << depth, (batch * (ny + 2 * nc),), dtype=torch.int32, device="cuda", generator=g).to(dt) for _ in range(pool)]
+
+            def ptrs(b):
+                p0 = b.data_ptr()
+                return p0, p0 + sz * batch * ny, p0 + sz * batch * (ny + nc)
+
+            def step(i):
+                y, u, v = ptrs(sets[i % pool])
+                h.add_grain_frames_dev(y, u, v, w, hh, w, cw, batch, sz * ny, sz * nc, stream)
+            t0, n = time.perf_counter(), 0
+            while (time.perf_counter() - t0) * 1e3 < 40.0:          # untimed pre-roll
+                for _ in range(8):
+                    step(n)
+                    n += 1
+                torch.cuda.synchronize()
+            per_launch_ms = (time.perf_counter() - t0) * 1e3 / n
+            steps = max(20, min(400, int(steps_ms / per_launch_ms)))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(steps):
+                step(i)
+            e1.record()
+            torch.cuda.synchronize()
+            launch_us = e0.elapsed_time(e1) / steps * 1e3
+            info = h.last_launch_info()
+            # parity of the timed shape: fresh frames, reset seed state, every frame against the oracle
+            h.lib.vfgs_hip_reset_state()
+            T.replay(h, rec)
+            ora = T.OracleHW()
+            T.replay(ora, rec)
+            gp = torch.Generator(device="cuda").manual_seed(4242)
+            sets[0].copy_(torch.randint(0, 1 << depth, (batch * (ny + 2 * nc),), dtype=torch.int32, device="cuda", generator=gp).to(dt))
+            src = sets[0].cpu().numpy().view(npdt)
+            step(0)
+            torch.cuda.synchronize()
+            got = sets[0].cpu().numpy().view(npdt)
+            bad = 0
+            for f in range(batch):
+                fr = T.Frame(w, hh, depth, sx, sy, stride=w, cstride=cw)
+                yo, uo, vo = f * ny, batch * ny + f * nc, batch * (ny + nc) + f * nc
+                fr.Y[:hh] = src[yo:yo + ny].reshape(hh, w)           # (1080 lines: the allocation is padded to 1088, yuv.c:54-87)
+                fr.U[:ch] = src[uo:uo + nc].reshape(ch, cw)
+                fr.V[:ch] = src[vo:vo + nc].reshape(ch, cw)
+                ora.add_grain_frame(fr)
+                bad += not (np.array_equal(fr.Y[:hh].ravel(), got[yo:yo + ny]) and np.array_equal(fr.U[:ch].ravel(), got[uo:uo + nc])
+                            and np.array_equal(fr.V[:ch].ravel(), got[vo:vo + nc]))
+            parity = bad == 0 and h.seed_state() == ora.seed_state()
+            nbytes = 2 * frame_bytes * batch
+            gbs = nbytes / (launch_us * 1e-6) / 1e9
+            out.append({"workload": name + ", seed 12345, uniform random samples", "frames_per_launch": batch, "steps": steps,
+                        "launch_us": round(launch_us, 2), "algorithmic_bytes_per_launch": nbytes, "achieved": round(gbs, 1),
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "mpixels_per_s": round(batch * w * hh / launch_us, 1),
+                        "kernel": info["kernel"] if info else None, "workgroups_per_frame": info["workgroups_per_frame"] if info else None,
+                        "parity_checked": bool(parity)})
+            del sets
+            torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -120,6 +223,7 @@ def main():
                     help="weak: a step is gpus*batch frames; strong: a step is batch frames split over the ranks")
     ap.add_argument("--no-region", action="store_true", help="skip the second leg (the same launches inside an overlap region)")
     ap.add_argument("--no-parity", action="store_true", help="skip the post-timing parity launch")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json configs[0..3] leg (N=1 only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -217,6 +321,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     launch_ms = ev0.elapsed_time(ev1) / args.steps     # same stream as the kernels (torch's current stream)
+    launch_info = h.last_launch_info()                 # what the timed launches dispatched (the library's own record)
 
     # ---- second leg (reported beside the contract's numbers, never as them): the same K launches inside an overlap region
     # (include/vfgs_hip.h: independent frames, the library alternates two internal streams, so one launch's tail overlaps the
@@ -333,16 +438,18 @@ def main():
         tf = ROOT / "profiles" / "hbm_traffic.json"
         if tf.exists() and world == 1:
             rec = json.loads(tf.read_text())
-            if rec.get("batch") == args.batch and rec.get("kernel_sha16") == kernel_sha():
+            if rec.get("batch") == args.batch and rec.get("kernel_sha16") == kernel_sha() and rec.get("sources") == list(PROFILED_SOURCES):
                 traffic = rec.get("bytes_per_launch")
-                traffic_source = {"file": "profiles/hbm_traffic.json", "date": rec.get("date"), "kernel_sha16": rec.get("kernel_sha16"),
-                                  "how": rec.get("correction")}
+                traffic_source = {"file": "profiles/hbm_traffic.json", "stale": False, "date": rec.get("date"), "kernel_sha16": rec.get("kernel_sha16"),
+                                  "sources": rec.get("sources"), "how": rec.get("correction")}
             else:
                 traffic_source = {"file": "profiles/hbm_traffic.json", "stale": True, "kernel_sha16_now": kernel_sha(),
-                                  "kernel_sha16_profiled": rec.get("kernel_sha16")}
+                                  "kernel_sha16_profiled": rec.get("kernel_sha16"), "sources": list(PROFILED_SOURCES)}
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "grain_rw_kernel<10,2,2,false,true> (depth 10, 4:2:0, in place; luma general form, chroma one-pattern form; row walk, aligned nontemporal accesses)", "launch_us": round(launch_ms * 1e3, 2),
+                "kernel": launch_info["kernel"] if launch_info else None,
+                "kernel_launch": launch_info,       # vfgs_hip_last_launch_info(): form of the table image, workgroups, rows per wave ...
+                "launch_us": round(launch_ms * 1e3, 2),
                 "algorithmic_bytes_per_launch": bytes_per_launch}
         if region is not None:
             roof["overlap_region"] = {"launch_us": round(region * 1e3, 2), "achieved": round(bytes_per_launch / (region * 1e-3) / 1e9, 1),
@@ -374,11 +481,22 @@ def main():
             "roofline": roof,
             "parity_checked": parity,
         }
+        if world == 1 and not args.no_configs:
+            out["configs"] = bench_configs(h, stream)
+            if not all(c["parity_checked"] for c in out["configs"]):
+                parity = False
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
+        if parity is False:
+            # a kernel that produced wrong bytes gets no benchmark line: the numbers are withheld and the exit code says so
+            bad_cfg = [c["workload"] for c in out.get("configs", []) if not c["parity_checked"]]
+            out = {"metric": out["metric"], "error": "parity failure: output differs from the oracle", "parity_checked": False,
+                   "n_gpus": world, "failed_configs": bad_cfg}
         print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if parity is False:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

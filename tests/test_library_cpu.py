@@ -108,7 +108,7 @@ def test_header_is_valid_c_and_links(lib, tmp_path):
                     f"-L{libdir}", "-lvfgs_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "49 entry points" in r.stdout and "0x00006072" in r.stdout
+    assert "50 entry points" in r.stdout and "0x00006072" in r.stdout
 
 
 def test_product_library_is_not_a_developer_build(lib):
@@ -120,7 +120,7 @@ def test_product_library_is_not_a_developer_build(lib):
     assert "diag" not in header
 
 
-@pytest.mark.parametrize("flag", ["-DVFGS_ABLATE=1", "-DVFGS_RW_ABLATE=1", "-DVFGS_WAVES=8", "-DVFGS_NO_ROWWALK", "-DVFGS_LDAUX_ALIGNED=0"])
+@pytest.mark.parametrize("flag", ["-DVFGS_WAVES=8", "-DVFGS_RW_CONSEC=1", "-DVFGS_NO_FRONTS", "-DVFGS_LDAUX_ALIGNED=0"])
 def test_a_stray_knob_is_a_build_error(flag, tmp_path):
     """A -D that changes what the kernels compute (or how) must not produce a product library: without VFGS_DEV_BUILD the
     layout header refuses it at compile time."""

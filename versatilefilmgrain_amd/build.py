@@ -50,7 +50,8 @@ def build_diag(force: bool = False) -> Path:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    build_diag(force)
+    # (the bench-only diagnostics library is built where it is used -- bench.py, tools/dev/clocks_under_load.sh call
+    # build_diag() -- not here: the product build must not depend on tools/ being present, or on that file compiling)
     if up_to_date() and not force:
         return LIB
     with tempfile.TemporaryDirectory(prefix="vfgs_build_") as tmp:

@@ -29,6 +29,7 @@ bool aligned_ok(int depth, int csubx, int nblk, bool out8);
 bool rowwalk_ok(int depth, int csubx, int nblk, bool out8);
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
 void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes);
+void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int aligned);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
 hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby,
                            bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, hipStream_t stream);
@@ -554,6 +555,9 @@ State& S()
 
 std::mutex g_mu;
 
+vfgs_hip_launch_info g_last_launch{};      // what the primary state's most recent grain launch dispatched
+bool g_last_launch_valid = false;
+
 int ensure_init(int device)
 {
 	State& s = S();
@@ -1076,6 +1080,30 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.lfronts = (rowwalk && nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
 #endif
 	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, rowwalk ? 2 : (aligned ? 1 : 0), (int)per_frame, stream));
+	if (&s == &g_states[0])
+	{
+		vfgs_hip_launch_info& li = g_last_launch;
+		const unsigned long long n = li.launches + 1;
+		li = vfgs_hip_launch_info{};
+		li.launches = n;
+		li.depth = 8 + s.bs; li.csubx = s.csubx; li.csuby = s.csuby;
+		li.out8 = dg.out8; li.one_y = s.img_one_y; li.one_c = s.img_one_c;
+		li.in_place = (sY == dY && sU == dU && sV == dV);
+		li.nframes = (int)nframes;
+		li.workgroups_per_frame = (int)per_frame;
+		li.frames_per_front = 1 << a.lfronts;
+		for (int pt = 0; pt < 2; pt++)
+		{
+			li.rows_per_wave[pt] = rowwalk ? a.pd[pt].rw_rpw : rows_per_wave;
+			li.positions_per_row[pt] = rowwalk ? a.pd[pt].rw_segs : a.pd[pt].segs;
+		}
+		li.parts_per_row = 1;
+		li.waves_per_workgroup = vfgs::kWavesPerWG;
+		const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, s.img_one_y, s.img_one_c);
+		li.lds_bytes_per_workgroup = L.lds_bytes + (rowwalk ? vfgs::kParamBytes : 0);
+		vfgs::describe_launch(li.kernel, sizeof li.kernel, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, rowwalk ? 2 : (aligned ? 1 : 0));
+		g_last_launch_valid = true;
+	}
 	return 0;
 }
 
@@ -1762,11 +1790,12 @@ void vfgs_hip_reset_state(void)
 	s.seed_epoch++;
 	s.rnd = s.rnd_up = s.line_rnd = s.line_rnd_up = 0;
 	s.tables_dirty = true;
-	if (s.ov.active)   // a region left open (a caller that failed between _begin and _end): join it
-	{
-		s.ov.active = false;
+	if (s.ov.active)   // a region left open (a caller that failed between _begin and _end): drain its internal streams on the host --
+	{                  // the stream it was opened on is the caller's and may be gone by now, so it is not touched
 		for (int i = 0; i < 2; i++)
-			if (hipEventRecord(s.ov.join[i], s.ov.s[i]) == hipSuccess) (void)hipStreamWaitEvent(s.ov.user, s.ov.join[i], 0);
+			if (s.ov.s[i]) (void)hipStreamSynchronize(s.ov.s[i]);
+		s.ov.active = false;
+		s.ov.user = nullptr;
 	}
 }
 
@@ -1811,12 +1840,23 @@ int vfgs_hip_overlap_end(void* stream)
 	if (int e = ensure_init(-1)) return e;
 	State& s = S();
 	if (!s.ov.active || s.ov.user != (hipStream_t)stream) return fail(27, "vfgs_hip_overlap_end: no region open on this stream");
-	s.ov.active = false;
+	// both joins are attempted whatever the first one returns; a join that cannot be queued is replaced by waiting for that
+	// internal stream on the host, so that work queued on `stream` after this call never runs ahead of the region's launches;
+	// only then is the region closed, and the first error (if any) reported
+	hipError_t first = hipSuccess;
 	for (int i = 0; i < 2; i++)
 	{
-		HIP_TRY(hipEventRecord(s.ov.join[i], s.ov.s[i]));
-		HIP_TRY(hipStreamWaitEvent(s.ov.user, s.ov.join[i], 0));
+		hipError_t e = hipEventRecord(s.ov.join[i], s.ov.s[i]);
+		if (e == hipSuccess) e = hipStreamWaitEvent(s.ov.user, s.ov.join[i], 0);
+		if (e != hipSuccess)
+		{
+			(void)hipStreamSynchronize(s.ov.s[i]);
+			if (first == hipSuccess) first = e;
+		}
 	}
+	s.ov.active = false;
+	s.ov.user = nullptr;
+	HIP_TRY(first);
 	return 0;
 }
 
@@ -2029,6 +2069,14 @@ void vfgs_hip_get_stream_stats(uint64_t out[4])
 {
 	std::lock_guard<std::mutex> g(g_mu);
 	S().lfsr.stats(out);
+}
+
+int vfgs_hip_last_launch_info(vfgs_hip_launch_info* out)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	if (!out || !g_last_launch_valid) return -1;
+	*out = g_last_launch;
+	return 0;
 }
 
 int vfgs_hip_last_error(void) { return g_err; }

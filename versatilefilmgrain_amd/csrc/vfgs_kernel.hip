@@ -29,6 +29,7 @@
 //     one-byte-per-sample bank (ONEY / ONEC kernels, vfgs_layout.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include <type_traits>
 
@@ -174,9 +175,6 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	constexpr int NS = DEPTH == 8 ? 16 : 8;
 	using M = LaneMap<NS, BW>;
 	constexpr int NR = M::NR, NQ = M::NQ;
-#if VFGS_ABLATE >= 1 && VFGS_ABLATE <= 4
-	return;
-#endif
 	// unpack the block parameters
 	int sg[NR];              // 0 / -1: the block's sign is negative
 	uint32_t ad[NR], k2s[NR];
@@ -187,7 +185,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		// one-pattern form: the address of a negative block (of the CURRENT row of blocks; `up` is only used on overlap lines)
 		// points into the negated bank (vfgs_layout.h); the overlap lines blend true values by signed weights: back to the bank
 		ad[r] = (rp.pa[r] & 0xffffu) + rowoff - ((ONE && OVERLAP) ? ((uint32_t)sg[r] & (uint32_t)NEG) : 0u);
-		k2s[r] = ONE ? 0u : ((OVERLAP || (VFGS_XABLATE & 1)) ? lutb : (((uint32_t)sg[r] & 0x04000400u) | lutb));     // OVERLAP: the +scale table
+		k2s[r] = ONE ? 0u : (OVERLAP ? lutb : (((uint32_t)sg[r] & 0x04000400u) | lutb));     // OVERLAP: the +scale table
 	}
 	uint32_t e[NS];
 	int P[NS];
@@ -197,10 +195,6 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	for (int q = 0; q < NQ; q++)
 	{
 		const uint32_t k2 = k2s[M::run(q)];
-#if VFGS_ABLATE == 8
-#pragma unroll
-		for (int i = 0; i < 4; i++) e[4 * q + i] = (w[q * 4 / (NS / 4)] << (3 * i)) ^ k2;
-#else
 		if (DEPTH > 8)
 		{
 #pragma unroll
@@ -214,19 +208,11 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		else
 		{
 			const uint32_t v = w[q], k1 = k2 & 0xffffu;
-#if VFGS_XABLATE & (64 | 128)     // probe: the table replicated over 8 / 16 banks (addresses only; WRONG values)
-			constexpr int LR = (VFGS_XABLATE & 64) ? 3 : 4;
-			const uint32_t lanec = ((threadIdx.x & ((1u << LR) - 1)) << 2) | (k1 & 0);
-#pragma unroll
-			for (int i = 0; i < 4; i++) e[4 * q + i] = *(const uint32_t*)(lds + (((((v >> (8 * i)) & 0xffu) << (2 + LR)) | lanec) & 0x3fffu));
-			if (false)
-#endif
 			e[4 * q + 0] = *(const uint32_t*)(lds + (((v << 2) & 0x3fcu) | k1));
 			e[4 * q + 1] = *(const uint32_t*)(lds + (((v >> 6) & 0x3fcu) | k1));
 			e[4 * q + 2] = *(const uint32_t*)(lds + (((v >> 14) & 0x3fcu) | k1));
 			e[4 * q + 3] = *(const uint32_t*)(lds + (((v >> 22) & 0x3fcu) | k1));
 		}
-#endif
 	}
 
 	// pattern fetch.  General form: 4 samples x 8 slots = 32 bytes per quad, the sample's slot picked by v_perm_b32.
@@ -245,21 +231,11 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 			else
 				d = *(const uint32_t*)(lds + adq + M::col(q));
 #pragma unroll
-			for (int i = 0; i < 4; i++) out[i] = (VFGS_XABLATE & 4) ? (int)d + i : (int)(d << (24 - 8 * i)) >> 24;
+			for (int i = 0; i < 4; i++) out[i] = (int)(d << (24 - 8 * i)) >> 24;
 		}
 		else
 		{
-#if VFGS_ABLATE == 9
-			const u32x4 c0 = {adq, adq * 3, adq * 5, adq * 7}, c1 = {adq ^ 77, adq + 99, adq * 9, adq * 11};
-#else
-#if VFGS_XABLATE & 32      // probe: four 8-byte reads instead of two 16-byte reads at 8-byte aligned addresses
-			const u32x2* hp = (const u32x2*)__builtin_assume_aligned(lds + adq + M::col(q) * kSlots, 8);
-			const u32x2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
-			const u32x4 c0 = {h0.x, h0.y, h1.x, h1.y}, c1 = {h2.x, h2.y, h3.x, h3.y};
-#else
 			const u32x4 c0 = *(const u32x4*)(lds + adq + M::col(q) * kSlots), c1 = *(const u32x4*)(lds + adq + M::col(q) * kSlots + 16);
-#endif
-#endif
 			out[0] = pick_slot(c0.y, c0.x, e[4 * q + 0]); out[1] = pick_slot(c0.w, c0.z, e[4 * q + 1]);
 			out[2] = pick_slot(c1.y, c1.x, e[4 * q + 2]); out[3] = pick_slot(c1.w, c1.z, e[4 * q + 3]);
 		}
@@ -292,8 +268,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	// 3-tap filter across the block edge (vfgs_hw.c:250-259), on unfiltered neighbours
 	// (all values are small: explicit 24-bit multiply-adds; the compiler otherwise reaches for 32/64-bit
 	// multiplies and turns the selects into a branch that copies all the P registers)
-	if (VFGS_XABLATE & 16) {}
-	else if (M::PAIR)
+	if (M::PAIR)
 	{
 		const int mine = first ? P[0] : P[7];
 		const int inner = first ? P[1] : P[6];
@@ -347,11 +322,8 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		if (DEPTH > 8)  // a 16-bit container may hold anything: keep the add inside int16 (result is clipped anyway)
 			v = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, v), __builtin_bit_cast(u16x2, 0x70007000u)));
 		s16x2 s = __builtin_bit_cast(s16x2, v) + __builtin_bit_cast(s16x2, gp);
-		if (!(VFGS_XABLATE & 2))
-		{
-			s = __builtin_elementwise_max(s, __builtin_bit_cast(s16x2, lo2));
-			s = __builtin_elementwise_min(s, __builtin_bit_cast(s16x2, hi2));
-		}
+		s = __builtin_elementwise_max(s, __builtin_bit_cast(s16x2, lo2));
+		s = __builtin_elementwise_min(s, __builtin_bit_cast(s16x2, hi2));
 		return __builtin_bit_cast(uint32_t, s);
 	};
 	if (DEPTH > 8)
@@ -405,9 +377,6 @@ __device__ __forceinline__ void store_data_hazard()
 template <int AUX = VFGS_STAUX>
 __device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, const uint32_t (&w)[4])
 {
-#if VFGS_ABLATE == 5   // (almost) never store: keeps the math alive, drops the write traffic
-	if (!(w[0] == 0x12345678u && w[3] == 0x9abcdef0u)) return;
-#endif
 	const u32x4 t = {w[0], w[1], w[2], w[3]};
 	__builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, AUX);
 	store_data_hazard();
@@ -425,9 +394,6 @@ __device__ __forceinline__ void load_dwords(__amdgpu_buffer_rsrc_t rs, uint32_t 
 template <int N, int AUX>
 __device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, const uint32_t* w)
 {
-#if VFGS_ABLATE == 5
-	if (!(w[0] == 0x12345678u)) return;
-#endif
 	if (N == 4) { const u32x4 t = {w[0], w[1], w[2], w[3]}; __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, AUX); store_data_hazard(); }
 	else if (N == 3) { const u32x3 t = {w[0], w[1], w[2]}; __builtin_amdgcn_raw_buffer_store_b96(t, rs, voff, soff, AUX); store_data_hazard(); }
 	else if (N == 2) { const u32x2 t = {w[0], w[1]}; __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, AUX); }
@@ -444,7 +410,7 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	constexpr int NR = M::NR;
 	constexpr int RPB = 16 / SUBY;                       // rows of this plane per block row
 	constexpr int NEF = M::PAIR ? 1 : M::NE;
-	constexpr bool PARTIAL = !AL && !M::PAIR && VFGS_ABLATE != 4;   // rows of this plane type begin and end with a partly valid lane
+	constexpr bool PARTIAL = !AL && !M::PAIR;   // rows of this plane type begin and end with a partly valid lane
 	constexpr int K = M::SHIFT * SZ / 4;                 // aligned mode: dwords of a lane that lie in the memory unit before the lane's own
 	constexpr int LDA = AL ? VFGS_LDAUX_ALIGNED : VFGS_LDAUX, STA = AL ? VFGS_STAUX_ALIGNED : VFGS_STAUX;
 	static_assert(!(AL && OUT8), "the narrowed destination keeps the shifted accesses");
@@ -592,14 +558,12 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 	constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
 	static_assert(IMG_BYTES % 16 == 0, "table image in whole 16-byte units");
 	u32x4 tmp[NIT];
-#if VFGS_ABLATE != 2
 	{
 		const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.tables + img_off, IMG_BYTES);
 #pragma unroll
 		for (int it = 0; it < NIT; it++)      // threads beyond the image re-read (and re-write) its last unit
 			tmp[it] = __builtin_amdgcn_raw_buffer_load_b128(irs, min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16)), 0, 0);
 	}
-#endif
 	u32x2 wcur[4][NR], wup[4][NR];
 	{
 		const __amdgpu_buffer_rsrc_t strs_up = make_rsrc((const uint8_t*)a.stream, any_up ? a.stream_bytes : 0);
@@ -608,12 +572,8 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 #pragma unroll
 			for (int rr = 0; rr < NR; rr++)
 			{
-#if VFGS_ABLATE == 3
-				wcur[g][rr] = u32x2{(uint32_t)blk[g][rr], 7u}; wup[g][rr] = wcur[g][rr];
-#else
 				wcur[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs, ((cur_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
 				wup[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs_up, ((up_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
-#endif
 			}
 	}
 	// aligned mode: the last K dwords of the unit before the tile are this wave's (lane 0 of segment 0 computes them), the
@@ -631,11 +591,9 @@ __device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& 
 		for (int g = 0; g < 4; g++) load_seg<LDA>(frs, vo[g], rowb, w[g]);
 		if (AL) load_dwords<K, LDA>(frs, preoff, rowb, pre);
 	}
-#if VFGS_ABLATE != 2
 #pragma unroll
 	for (int it = 0; it < NIT; it++)
 		*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
-#endif
 	__syncthreads();
 	if (k0 >= k1)
 		return;
@@ -878,17 +836,12 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	constexpr int STEP = kWavesPerWG * 64 * 16;
 	constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
 	u32x4 tmp[NIT];
-#if VFGS_RW_ABLATE >= 2
-#pragma unroll
-	for (int it = 0; it < NIT; it++) tmp[it] = u32x4{1, 2, 3, 4};
-#else
 	{
 		const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.tables + img_off, IMG_BYTES);
 #pragma unroll
 		for (int it = 0; it < NIT; it++)      // threads beyond the image re-read (and re-write) its last unit
 			tmp[it] = __builtin_amdgcn_raw_buffer_load_b128(irs, min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16)), 0, 0);
 	}
-#endif
 	// parameter table entry e = block e - 1 (clamped into the row): thread t fills entries t, t + 256, ...
 	constexpr int NPE = (kParamEntries + kWavesPerWG * 64 - 1) / (kWavesPerWG * 64);
 	u32x2 wc[NPE], wu[NPE];
@@ -900,11 +853,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 		{
 			const int e = (int)threadIdx.x + i * kWavesPerWG * 64;
 			const uint32_t blk = (uint32_t)min(max(e - 1, 0), last);
-#if VFGS_RW_ABLATE >= 3
-			const bool need = false;
-#else
 			const bool need = e < a.nblk + 4 && e < kParamEntries;
-#endif
 			wc[i] = __builtin_amdgcn_raw_buffer_load_b64(strs, need ? ((cur_bit + blk) >> 5) * 4 : kOOB, 0, 0);
 			wu[i] = __builtin_amdgcn_raw_buffer_load_b64(strs_up, need ? ((up_bit + blk) >> 5) * 4 : kOOB, 0, 0);
 		}
@@ -942,11 +891,9 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 			load_seg<LDA>(rs0, lane16 + (u % NARROW) * (kMaxUnits * 16), 0, w[u]);
 		}
 	}
-#if VFGS_RW_ABLATE < 2
 #pragma unroll
 	for (int it = 0; it < NIT; it++)
 		*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
-#endif
 
 	// ---- block parameters of the row (once per workgroup) ----------------------------------------------------------
 	const int fsx = comp == 0 ? 0 : (comp == 1 ? 10 : 20);
@@ -985,17 +932,10 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	const int cl = M::PAIR ? lane - 1 - (lane & 1) : lane * LPB - 1;       // PAIR: left unit of my lane pair; else: block of run 0 (both for segment 0)
 	constexpr int SSTEP = M::PAIR ? 64 : BPS;                              // what `cl` advances by per segment
 	// DPP moves by one lane; lanes without a source lane (lane 0 / lane 63) keep `old`; the rotations wrap around
-#if VFGS_XABLATE & 8
-	auto lane_up = [](uint32_t old, uint32_t v) { return v; };
-	auto lane_down = [](uint32_t old, uint32_t v) { return v; };
-	auto rot_up = [](uint32_t v) { return v; };
-	auto rot_down = [](uint32_t v) { return v; };
-#else
 	auto lane_up = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false); };    // wave_shr:1: lane l <- lane l - 1
 	auto lane_down = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130, 0xf, 0xf, false); };  // wave_shl:1: lane l <- lane l + 1
 	auto rot_up = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13c, 0xf, 0xf, false); };      // wave_ror:1: lane 0 <- lane 63
 	auto rot_down = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134, 0xf, 0xf, false); };    // wave_rol:1: lane 63 <- lane 0
-#endif
 
 	// ---- the walk ----------------------------------------------------------------------------------------------------
 	uint32_t carry[4] = {0, 0, 0, 0};      // in lane 0: the last K dwords of lane 63 of the previous segment of the row
@@ -1119,11 +1059,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 				for (int d = K; d < 4; d++) asm volatile("v_mov_b32 %0, %1" : "=v"(t[d]) : "v"(w[u][d - K]));
 				// the registers are free: refill them with the segment four steps ahead
 				load_seg<LDA>(nsrc, lane16 + u * (kMaxUnits * 16), 0, w[u]);
-#if VFGS_RW_ABLATE >= 1       // timing experiments only (tools/dev/build_variant.sh): copy, WRONG output
-				if (false)
-#else
 				if (NU * g + u < tsegs)
-#endif
 				{
 					bool edge_on[NEF];
 					if (M::PAIR)
@@ -1296,6 +1232,15 @@ hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bo
 	VFGS_CASE(8, 2, 2);  VFGS_CASE(8, 2, 1);  VFGS_CASE(8, 1, 1);  VFGS_CASE(8, 1, 2);
 #undef VFGS_CASE
 	return hipErrorInvalidValue;
+}
+
+// the name of the instantiation launch_grain() dispatches for these arguments, as the profiler prints it (vfgs_hip_last_launch_info)
+void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int aligned)
+{
+	auto b = [](bool v) { return v ? "true" : "false"; };
+	if (depth == 10 && out8) snprintf(out, n, "grain_kernel<10,%d,%d,true,false,false,false>", csubx, csuby);
+	else if (VFGS_ALIGNED && aligned == 2) snprintf(out, n, "grain_rw_kernel<%d,%d,%d,%s,%s>", depth, csubx, csuby, b(oney), b(onec));
+	else snprintf(out, n, "grain_kernel<%d,%d,%d,false,%s,%s,%s>", depth, csubx, csuby, b(oney), b(onec), b(VFGS_ALIGNED && aligned == 1));
 }
 
 // may a launch use the aligned kernels?  (rows of both plane types are whole 16-byte units; not the narrowed destination)

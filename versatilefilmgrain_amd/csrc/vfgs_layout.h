@@ -10,7 +10,9 @@ constexpr int kMaxUnits = 64;    // 16-byte units per segment (one per lane)
 constexpr int kSegsPerTile = 4;  // segments a wave moves per row
 constexpr int kBlock = 16;       // luma samples per grain block
 
-// Tuning knobs (defaults are the shipped configuration; tools/ablate.py overrides them).
+// Tuning knobs (defaults are the shipped configuration; tools/dev/build_variant.sh overrides them).  They change HOW the
+// kernels run, never WHAT they compute: the timing-only probes with wrong output that rounds 2 and 3 kept in the kernel source
+// (their results: profiles/r02_variants*.log, r03_ab*.log) were removed in round 4.
 #ifndef VFGS_WAVES
 #define VFGS_WAVES 4          // waves per workgroup (power of two); they share one LDS image
 #endif
@@ -38,12 +40,6 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_SPLIT_INTERLEAVE
 #define VFGS_SPLIT_INTERLEAVE 0   // 1: the workgroups that share a block row take every splits-th row instead of consecutive rows
 #endif
-#ifndef VFGS_ABLATE
-#define VFGS_ABLATE 0     // 0 = product.  >0: timing-only variants with WRONG output (tools/ablate.py):
-                          //   1 copy only (tables still staged, block parameters still computed), 2 copy only + no staging,
-                          //   3 copy only + no LFSR loads, 4 copy only + partly valid lanes ignored,
-                          //   5 no stores, 8 no LUT gather, 9 no pattern fetch
-#endif
 #ifndef VFGS_ALIGNED
 #define VFGS_ALIGNED 1        // 1: whole aligned 16-byte units are moved (1 KiB line-aligned wave accesses) and rotated by one lane in
                               //    registers; 0: every lane loads and stores the shifted 16 bytes it computes (round 2's first form)
@@ -62,22 +58,14 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #define VFGS_RW_CONSEC 0      // row walk: 1 = a wave's rows are consecutive, 0 = the waves of a workgroup take every kWavesPerWG-th row
 #endif
 
-#ifndef VFGS_RW_ABLATE
-#define VFGS_RW_ABLATE 0      // row-walk kernels: 0 = product; 1..3 timing-only variants with WRONG output (tools/dev/build_variant.sh)
-#endif
-
-#ifndef VFGS_XABLATE
-#define VFGS_XABLATE 0        // bit mask of timing-only probes with WRONG output (what would an instruction saved be worth?): 1 = no sign table
-#endif                        // select, 2 = no clip, 4 = pattern bytes not extracted, 8 = no lane rotation, 16 = no edge filter
-
 // The product is built with every knob at its default (versatilefilmgrain_amd/build.py passes none).  The developer tools that
-// time variants (tools/dev/build_variant.sh, tools/gpu_variants.sh, tools/ablate.py) define VFGS_DEV_BUILD; without it any
+// time variants (tools/dev/build_variant.sh, tools/gpu_variants.sh) define VFGS_DEV_BUILD; without it any
 // other value is a build error, so a stray -D cannot produce a library that silently computes something else -- and a
 // developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
 #if !defined(VFGS_DEV_BUILD)
 #if VFGS_WAVES != 4 || VFGS_ROWS_PER_WAVE != 4 || VFGS_WG_PER_CU != 4 || VFGS_WG_PER_CU_8BIT_SUB != 3 || VFGS_LDAUX != 0 || VFGS_STAUX != 0 || \
-    VFGS_PREFETCH != 1 || VFGS_SCHED_FENCE != 1 || VFGS_SPLIT_INTERLEAVE != 0 || VFGS_ABLATE != 0 || VFGS_ALIGNED != 1 || VFGS_LANE_SHIFT_DPP != 1 || \
-    VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || VFGS_RW_ABLATE != 0 || VFGS_XABLATE != 0 || defined(VFGS_NO_ROWWALK) || defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || \
+    VFGS_PREFETCH != 1 || VFGS_SCHED_FENCE != 1 || VFGS_SPLIT_INTERLEAVE != 0 || VFGS_ALIGNED != 1 || VFGS_LANE_SHIFT_DPP != 1 || \
+    VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || defined(VFGS_NO_ROWWALK) || defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || \
     defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_ALIGN_TEST) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_MIN_FILL_PCT) || defined(VFGS_RW_MIN_FILL_PCT)
 #error "libvfgs_hip: a tuning / ablation knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif

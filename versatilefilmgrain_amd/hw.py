@@ -29,7 +29,7 @@ def _share_hip_runtime_with_torch() -> None:
     torch first).  Without torch (a C host) nothing happens and /opt/rocm's runtime is used."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("VFGS_HIP_NO_TORCH_RUNTIME"):     # (opt out: a Python host that will never import torch)
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -45,6 +45,21 @@ def _share_hip_runtime_with_torch() -> None:
             pass
 
 
+def hip_runtimes_mapped() -> list[str]:
+    """Paths of every libamdhip64 mapped into this process (Linux): more than one means two HIP runtimes, and whichever
+    initialises second finds no device."""
+    out = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                if "libamdhip64" in path and path not in out:
+                    out.append(path)
+    except OSError:
+        pass
+    return out
+
+
 def load(path: Path | None = None) -> C.CDLL:
     """dlopen libvfgs_hip.so; raises (never falls back) when it has not been built."""
     global _lib
@@ -56,6 +71,12 @@ def load(path: Path | None = None) -> C.CDLL:
                            "(needs hipcc); there is no CPU fallback")
     _share_hip_runtime_with_torch()
     lib = C.CDLL(str(path))
+    rts = hip_runtimes_mapped()
+    if len(rts) > 1:
+        import warnings
+        warnings.warn(f"libvfgs_hip: {len(rts)} HIP runtimes are mapped into this process ({', '.join(rts)}): device calls of the one "
+                      "that initialises second will fail.  Import torch before loading the library, or set VFGS_HIP_NO_TORCH_RUNTIME=1 "
+                      "in a process that never imports torch.", RuntimeWarning, stacklevel=2)
     vp, u, i = C.c_void_p, C.c_uint, C.c_int
     lib.vfgs_set_luma_pattern.argtypes = [i, vp]
     lib.vfgs_set_chroma_pattern.argtypes = [i, vp]
@@ -98,11 +119,20 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_host_alloc.restype = vp
     lib.vfgs_hip_host_free.argtypes = [vp]
     lib.vfgs_hip_host_free.restype = None
+    lib.vfgs_hip_last_launch_info.argtypes = [C.POINTER(LaunchInfo)]
     # a library built by a developer tool with tuning / ablation knobs may compute something else by design: only on request
     if lib.vfgs_hip_dev_build() and not os.environ.get("VFGS_ALLOW_DEV_BUILD"):
         raise VfgsHipError(f"{path} is a developer build (tuning / ablation knobs); set VFGS_ALLOW_DEV_BUILD=1 to load it anyway")
     _lib = lib
     return lib
+
+
+class LaunchInfo(C.Structure):
+    """include/vfgs_hip.h: vfgs_hip_launch_info."""
+    _fields_ = [("depth", C.c_int), ("csubx", C.c_int), ("csuby", C.c_int), ("out8", C.c_int), ("one_y", C.c_int), ("one_c", C.c_int),
+                ("in_place", C.c_int), ("nframes", C.c_int), ("workgroups_per_frame", C.c_int), ("frames_per_front", C.c_int),
+                ("rows_per_wave", C.c_int * 2), ("positions_per_row", C.c_int * 2), ("parts_per_row", C.c_int),
+                ("waves_per_workgroup", C.c_int), ("lds_bytes_per_workgroup", C.c_int), ("launches", C.c_ulonglong), ("kernel", C.c_char * 96)]
 
 
 EXPORTS = [
@@ -117,7 +147,7 @@ EXPORTS = [
     "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
     "vfgs_hip_dev_build", "vfgs_hip_init_devices", "vfgs_hip_overlap_begin", "vfgs_hip_overlap_end", "vfgs_hip_get_stream_stats", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
-    "vfgs_hip_add_grain_frames_host", "vfgs_hip_host_alloc", "vfgs_hip_host_free",
+    "vfgs_hip_add_grain_frames_host", "vfgs_hip_host_alloc", "vfgs_hip_host_free", "vfgs_hip_last_launch_info",
 ]
 
 
@@ -241,6 +271,17 @@ class VfgsHip:
         """Host-memory frames and stripes are split over these devices from now on (devices[0] stays the library's device)."""
         arr = (C.c_int * len(devices))(*devices)
         self._ck(self.lib.vfgs_hip_init_devices(arr, len(devices)))
+
+    def last_launch_info(self):
+        """What the most recent grain launch dispatched (dict), or None before the first launch."""
+        li = LaunchInfo()
+        if self.lib.vfgs_hip_last_launch_info(C.byref(li)):
+            return None
+        d = {k: getattr(li, k) for k, _ in LaunchInfo._fields_ if k not in ("rows_per_wave", "positions_per_row", "kernel")}
+        d["rows_per_wave"] = list(li.rows_per_wave)
+        d["positions_per_row"] = list(li.positions_per_row)
+        d["kernel"] = li.kernel.decode()
+        return d
 
     def device_info(self):
         cu, lds, clk = C.c_int(), C.c_int(), C.c_int()
