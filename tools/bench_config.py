@@ -142,6 +142,8 @@ def main():
     us = launch_us / args.batch
     samples = w * hh * (1 + 2 / (sx * sy))
     nbytes = (sz + (1 if args.mode == "copy8" else sz)) * samples
+    info = h.last_launch_info()
+    kernel = info["kernel"] if info else kernel
     print(json.dumps({"config": args.config, "workload": name, "content": args.content, "mode": args.mode, "streams": args.streams, "overlap_region": bool(args.overlap), "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
                       "launch_us": round(launch_us, 2), "host_us_per_call": round(host_us, 2), "us_per_frame": round(us, 3), "algorithmic_bytes_per_frame": int(nbytes),
                       "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 4),

@@ -14,10 +14,11 @@ def rep(old, new):
 rep("namespace vfgs {\n", "namespace vfgs {\n__device__ unsigned long long g_tl[16];\n__device__ __forceinline__ unsigned long long tl_now() { return __builtin_amdgcn_s_memrealtime(); }\n")
 rep("	const int pt = comp ? 1 : 0;\n", "	const int pt = comp ? 1 : 0;\n	const unsigned long long tl0 = tl_now();\n	const bool tl_on = lane == 0 && comp == 0 && (blockIdx.x % 61) == 0;     // a sample of the luma waves: the marks must not disturb\n	auto tl_mark = [&](int i) { if (tl_on) atomicAdd(&g_tl[i], tl_now() - tl0); };\n")
 rep("	constexpr int STEP = kWavesPerWG * 64 * 16;\n", "	tl_mark(7);\n	constexpr int STEP = kWavesPerWG * 64 * 16;\n")
-rep("		if (AL) load_dwords<K, LDA>(frs, preoff, rowb, pre);\n	}\n", "		if (AL) load_dwords<K, LDA>(frs, preoff, rowb, pre);\n	}\n	tl_mark(8);\n")
-rep("	__syncthreads();\n	if (k0 >= k1)\n		return;\n", "	tl_mark(1);\n	__syncthreads();\n	tl_mark(2);\n	if (k0 >= k1)\n		return;\n")
-rep("	int k = k0;\n	if (any_up)", "	tl_mark(3);\n	if (tl_on) atomicAdd(&g_tl[0], 1ull);\n	int k = k0;\n	if (any_up)")
-rep("		for (; k < k1; k++)\n			row_any(std::false_type(), k, none, 0, 0);\n	}\n}", "		for (; k < k1; k++)\n		{\n			row_any(std::false_type(), k, none, 0, 0);\n			if (k == k0) tl_mark(4);\n		}\n	}\n	tl_mark(5);\n	__builtin_amdgcn_s_waitcnt(0);\n	tl_mark(6);\n}")
+rep("#pragma unroll\n	for (int it = 0; it < NIT; it++)\n		*(u32x4*)(lds + min(", "	tl_mark(8);\n#pragma unroll\n	for (int it = 0; it < NIT; it++)\n		*(u32x4*)(lds + min(")
+rep("	param_table(0, wc0, wu0);\n	__syncthreads();\n", "	param_table(0, wc0, wu0);\n	tl_mark(1);\n	__syncthreads();\n	tl_mark(2);\n	if (tl_on) atomicAdd(&g_tl[0], 1ull);\n")
+rep("			else walk_row(std::false_type(), k, g_lo, g_hi);\n", "			else walk_row(std::false_type(), k, g_lo, g_hi);\n			if (k == k0 && h == 0) tl_mark(4);\n")
+rep("	// the last position of my last row\n", "	tl_mark(5);\n	// the last position of my last row\n")
+rep("	store_unit<DW, STA>(pdst, laned + (NU - 1) * UBD, outp);\n}\n", "	store_unit<DW, STA>(pdst, laned + (NU - 1) * UBD, outp);\n	__builtin_amdgcn_s_waitcnt(0);\n	tl_mark(6);\n}\n")
 rep("ImageLayout layout_of(", "extern \"C\" int vfgs_hip_debug_timeline(unsigned long long* out, int reset)\n{\n	if (reset) { unsigned long long z[16] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tl), z, sizeof z); }\n	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), 16 * sizeof(unsigned long long));\n}\n\nImageLayout layout_of(")
 (ROOT / "tools/dev/vfgs_kernel_timeline.hip.txt").write_text(s)
 print("written")

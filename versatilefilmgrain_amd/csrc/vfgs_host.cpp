@@ -24,12 +24,9 @@
 #include "vfgs_layout.h"
 
 namespace vfgs {
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int aligned, int grid, hipStream_t stream);
-bool aligned_ok(int depth, int csubx, int nblk, bool out8);
-bool rowwalk_ok(int depth, int csubx, int nblk, bool out8);
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, int grid, hipStream_t stream);
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
-void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes);
-void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int aligned);
+void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
 hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby,
                            bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, hipStream_t stream);
@@ -43,15 +40,12 @@ __asm__(".section .rodata\n.balign 16\n.hidden vfgs_fw_blob\n.globl vfgs_fw_blob
 #endif
 extern "C" const unsigned char vfgs_fw_blob[], vfgs_fw_blob_end[];
 
-#ifndef VFGS_MIN_FILL_PCT
-#define VFGS_MIN_FILL_PCT 25   // tiled kernels: a launch should fill at least this share of the chip's wave slots (else: fewer rows per wave)
-#endif
 #ifndef VFGS_RW_MIN_FILL_PCT
-#define VFGS_RW_MIN_FILL_PCT 100  // row walk: ... of the wave slots (25 -> 100: single frames +2..8 %, 8-frame launches unchanged; 300 loses 10 % at
-#endif                            // 1080p x 8: profiles/r03_ab40_min_fill.log)
+#define VFGS_RW_MIN_FILL_PCT 100  // a launch should fill this share of the chip's wave slots, else its workgroups get half the rows (25 -> 100: single
+#endif                            // frames +2..8 %, 8-frame launches unchanged; 300 loses 10 % at 1080p x 8: profiles/r03_ab40_min_fill.log)
 #ifndef VFGS_RW_WG_BYTES
-#define VFGS_RW_WG_BYTES 24576 // row walk: a workgroup's rows should hold at least this many bytes (where its block row allows)
-#endif
+#define VFGS_RW_WG_BYTES 24576 // a workgroup's rows should hold at least this many bytes (where its block row allows; 16 KiB: the same, 48 KiB: -3..-13 %
+#endif                         // at 8 and at 32 frames per launch, profiles/r04_ab1_wg_bytes_vs_batch_and_tiny_launch_floor.log)
 
 namespace {
 
@@ -793,7 +787,8 @@ int check_luts(State& s)
 }
 
 // Which form of the table image (vfgs_layout.h) the current state gets.  want_general: the caller needs the general
-// (slot-interleaved) form even where one pattern would do (fused 8-bit output).  The pattern LUTs must have been digested.
+// (slot-interleaved) form even where one pattern would do (pictures wider than 8192 samples: their kernels exist in the general
+// form only).  The pattern LUTs must have been digested.
 void image_form(const State& s, bool want_general, bool* one_y, bool* one_c)
 {
 #ifdef VFGS_NO_ONE_PATTERN      // tools/gpu_variants.sh: always the general form
@@ -954,91 +949,51 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.nframes = (int)nframes;
 	a.lo2[0] = (uint32_t)(s.ymin << s.bs) * 0x10001u; a.hi2[0] = (uint32_t)(s.ymax << s.bs) * 0x10001u;
 	a.lo2[1] = (uint32_t)(s.cmin << s.bs) * 0x10001u; a.hi2[1] = (uint32_t)(s.cmax << s.bs) * 0x10001u;
-	// Rows a wave walks (its block parameters are computed once for them): vfgs::kRowsPerWave, fewer only for launches so
-	// small that they would leave most of the chip's wave slots empty (measured: 1080p single frames gain 14 %, anything
-	// that fills a quarter of the slots is faster with the full reuse).
-	int rows_per_wave = vfgs::kRowsPerWave;
-	const bool aligned = vfgs::aligned_ok(8 + s.bs, (int)s.csubx, (int)nblk, dg.out8);
-	const bool rowwalk = vfgs::rowwalk_ok(8 + s.bs, (int)s.csubx, (int)nblk, dg.out8);
-	int rw_shrink = 0;                      // row walk: halvings of the rows per wave (small launches)
+	// Geometry: a wave streams whole rows (positions = the row's units + the one behind them: the lanes compute bytes shifted
+	// by part of a unit); a workgroup = kWavesPerWG x rw_rpw rows of one block row, VFGS_RW_WG_BYTES where the block row allows.
+	// Launches that leave wave slots empty get workgroups of half the rows (single frames up to 2160p).
+	const unsigned nparts = (nblk + vfgs::kTileBlocks - 1) / vfgs::kTileBlocks;     // passes over the parameter table a row needs
+	int rw_shrink = 0;                      // halvings of the rows per wave (small launches)
 	bool form_one_y = false, form_one_c = false;   // the form the table image will have (upload_tables below)
 	digest_pluts(s);
-	if (image_is_current(s, dg.out8)) form_one_y = s.img_one_y;
-	else if (s.plut_bad_c < 0) image_form(s, dg.out8, &form_one_y, &form_one_c);
+	const bool wide = nparts > 1;           // the kernels of rows walked in parts exist in the general form only
+	if (image_is_current(s, wide)) form_one_y = s.img_one_y;
+	else if (s.plut_bad_c < 0) image_form(s, wide, &form_one_y, &form_one_c);
 	(void)form_one_c;
 	for (int pass = 0; pass < 3; pass++)
 	{
 		long waves = 0;
 		for (int pt = 0; pt < 2; pt++)
 		{
-			// geometry of the plane type: lanes of 16 bytes, segments of <= 64 lanes, tiles of 4 segments, and the
-			// shape of a workgroup (vfgs_layout.h PlaneDesc, vfgs_kernel.hip "Lanes")
 			vfgs::PlaneDesc& d = a.pd[pt];
 			const unsigned subx = pt ? s.csubx : 1, suby = pt ? s.csuby : 1;
 			const unsigned bw = 16 / subx, rpb = 16 / suby;
 			d.pitch = (pt ? cstride : stride) * sz;
 			d.dpitch = dg.out8 ? (pt ? dg.cstride : dg.stride) : d.pitch;
-			d.extent = (uint32_t)(pt ? cext : yext);
-			d.dextent = dg.out8 ? (uint32_t)(pt ? crows * dg.cstride : (uint64_t)part_h * dg.stride) : d.extent;
 			d.fpitch = pt ? cpitch : ypitch;
 			d.dfpitch = dg.out8 ? (pt ? dg.cpitch : dg.ypitch) : d.fpitch;
 			d.rowbytes = nblk * bw * sz;
 			d.drowbytes = dg.out8 ? nblk * bw : d.rowbytes;
 			d.nrows = pt ? (int)((part_y + part_h + suby - 1) / suby) - (int)((part_y + suby - 1) / suby) : (int)part_h;
 			auto lg = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
-			if (rowwalk)
-			{
-				// a wave streams whole rows: positions = the row's units + the one behind them (the lanes compute bytes shifted
-				// by part of a unit); a workgroup = kWavesPerWG x rw_rpw rows of one block row, about 60 KB where the block row allows
-				const int units = (int)((d.rowbytes + 15) / 16);       // (8-bit 4:2:x rows of an odd number of blocks end in half a unit)
-				d.rw_segs = (units + 1 + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
-				int rpw = 1;
-				// (8-bit luma in the general form -- per-sample pattern selection, 24 LDS instructions per position -- does better with
-				// waves of one row: +4 % at 2160p, profiles/r03_ab39_workgroup_bytes_8bit.log; every other form loses 4-7 % with them)
-				const size_t wg_bytes = (pt == 0 && s.bs == 0 && !form_one_y) ? VFGS_RW_WG_BYTES / 2 : VFGS_RW_WG_BYTES;
-				while (vfgs::kWavesPerWG * rpw * 2 <= (int)rpb && (size_t)vfgs::kWavesPerWG * rpw * d.rowbytes < wg_bytes) rpw *= 2;
-				for (int i = 0; i < rw_shrink && rpw > 1; i++) rpw /= 2;
-				d.rw_rpw = rpw;
-				d.rw_splits = std::max<int>(1, (int)rpb / (vfgs::kWavesPerWG * rpw));
-				d.rw_lsplits = lg(d.rw_splits);
-				d.wgs = d.nrows > 0 ? nbr_stripe * d.rw_splits : 0;
-				waves += (long)(pt ? 2 : 1) * d.wgs * vfgs::kWavesPerWG * nframes;
-				continue;
-			}
-			int shift_samples = 0, lanes = 0;
-			vfgs::lane_layout(8 + s.bs, (int)bw, (int)nblk, &shift_samples, &lanes);
-			d.segs = (lanes + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
-			d.upt = (lanes + d.segs - 1) / d.segs;
-			if (d.upt & 1) d.upt++;                     // even: the lanes of a pair (and their roles) stay together in every segment
-			if (aligned) d.upt = vfgs::kMaxUnits;       // whole aligned units: segment = 1 KiB of the row (the lanes compute bytes shifted against it)
-			d.tiles = (d.segs + vfgs::kSegsPerTile - 1) / vfgs::kSegsPerTile;
-			d.tiles_w = 1;
-			while (d.tiles_w < d.tiles && d.tiles_w < vfgs::kWavesPerWG) d.tiles_w *= 2;
-			d.colgroups = (d.tiles + d.tiles_w - 1) / d.tiles_w;
-			const int phases = vfgs::kWavesPerWG / d.tiles_w;
-			d.ppb = std::min<int>(phases, std::max<int>(1, (int)rpb / rows_per_wave));
-			d.bpw = phases / d.ppb;
-			d.splits = std::max<int>(1, (int)rpb / (d.ppb * rows_per_wave));
-			d.ltiles_w = lg(d.tiles_w); d.lppb = lg(d.ppb); d.lsplits = lg(d.splits);
-			const int nbgroups = (nbr_stripe + d.bpw - 1) / d.bpw;
-			d.wgs = d.nrows > 0 ? nbgroups * d.splits * d.colgroups : 0;
+			const int units = (int)((d.rowbytes + 15) / 16);       // (8-bit 4:2:x rows of an odd number of blocks end in half a unit)
+			d.rw_segs = (units + 1 + vfgs::kMaxUnits - 1) / vfgs::kMaxUnits;
+			int rpw = 1;
+			// (8-bit luma in the general form -- per-sample pattern selection, 24 LDS instructions per position -- does better with
+			// waves of one row: +4 % at 2160p, profiles/r03_ab39_workgroup_bytes_8bit.log; every other form loses 4-7 % with them)
+			const size_t wg_bytes = (pt == 0 && s.bs == 0 && !form_one_y) ? VFGS_RW_WG_BYTES / 2 : VFGS_RW_WG_BYTES;
+			while (vfgs::kWavesPerWG * rpw * 2 <= (int)rpb && (size_t)vfgs::kWavesPerWG * rpw * d.rowbytes < wg_bytes) rpw *= 2;
+			for (int i = 0; i < rw_shrink && rpw > 1; i++) rpw /= 2;
+			if (nparts > 1) rpw = 1;        // rows walked in parts (more than 512 blocks): the kernel's part loop assumes one row per wave
+			d.rw_rpw = rpw;
+			d.rw_splits = std::max<int>(1, (int)rpb / (vfgs::kWavesPerWG * rpw));
+			d.rw_lsplits = lg(d.rw_splits);
+			d.wgs = d.nrows > 0 ? nbr_stripe * d.rw_splits : 0;
 			waves += (long)(pt ? 2 : 1) * d.wgs * vfgs::kWavesPerWG * nframes;
 		}
-		const long slots = (long)s.cu_count * 16;          // wave slots of the chip at this kernel's occupancy
-		if (rowwalk)
-		{
-			// a launch that leaves most wave slots empty gets more, shorter workgroups
-			if (pass < 2 && waves * 100 < VFGS_RW_MIN_FILL_PCT * slots && (a.pd[0].rw_rpw > 1 || a.pd[1].rw_rpw > 1)) { rw_shrink++; continue; }
-			break;
-		}
-		if (pass == 0)
-		{
-			int r = rows_per_wave;
-			while (r > 1 && waves * rows_per_wave / r * 100 < VFGS_MIN_FILL_PCT * slots) r /= 2;
-			if (r == rows_per_wave) break;
-			rows_per_wave = r;
-		}
-		else break;
+		const long slots = (long)s.cu_count * 16;          // wave slots of the chip at the kernels' occupancy
+		if (pass < 2 && waves * 100 < VFGS_RW_MIN_FILL_PCT * slots && (a.pd[0].rw_rpw > 1 || a.pd[1].rw_rpw > 1)) { rw_shrink++; continue; }
+		break;
 	}
 
 	// seeds: every frame of the batch runs the full state machine; frame 0's part gives the offsets
@@ -1056,7 +1011,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	}
 	// Images are uploaded on the stream of the call that needs them first; a call on ANOTHER stream waits (once) for that
 	// upload, and a slot is only overwritten after all its readers (SlotGuard)
-	if (int e = upload_tables(s, stream, dg.out8)) return e;
+	if (int e = upload_tables(s, stream, wide)) return e;
 	if (int e = upload_stream(s, lo, hi, stream)) return e;
 	HIP_TRY(s.tables_ring.use(stream));
 	HIP_TRY(s.lfsr.use(stream));
@@ -1071,15 +1026,15 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
 	if (per_frame > 0x3fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;
-	// row walk, batches of large frames: two frames are swept at the same time (vfgs_kernel.hip grain_rw_kernel)
+	// batches of large frames: two frames are swept at the same time (vfgs_kernel.hip grain_rw_kernel)
 #ifdef VFGS_NO_FRONTS
 	a.lfronts = 0;
 #else
 	// (not inside an overlap region: there the second sweep is the launch on the other stream, and four fronts lose 15 %)
 	const bool in_region = g_states[0].ov.active && (stream == g_states[0].ov.s[0] || stream == g_states[0].ov.s[1]);
-	a.lfronts = (rowwalk && nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
+	a.lfronts = (nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
 #endif
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, rowwalk ? 2 : (aligned ? 1 : 0), (int)per_frame, stream));
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, (int)per_frame, stream));
 	if (&s == &g_states[0])
 	{
 		vfgs_hip_launch_info& li = g_last_launch;
@@ -1094,14 +1049,14 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		li.frames_per_front = 1 << a.lfronts;
 		for (int pt = 0; pt < 2; pt++)
 		{
-			li.rows_per_wave[pt] = rowwalk ? a.pd[pt].rw_rpw : rows_per_wave;
-			li.positions_per_row[pt] = rowwalk ? a.pd[pt].rw_segs : a.pd[pt].segs;
+			li.rows_per_wave[pt] = a.pd[pt].rw_rpw;
+			li.positions_per_row[pt] = a.pd[pt].rw_segs;
 		}
-		li.parts_per_row = 1;
+		li.parts_per_row = (int)nparts;
 		li.waves_per_workgroup = vfgs::kWavesPerWG;
 		const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, s.img_one_y, s.img_one_c);
-		li.lds_bytes_per_workgroup = L.lds_bytes + (rowwalk ? vfgs::kParamBytes : 0);
-		vfgs::describe_launch(li.kernel, sizeof li.kernel, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, rowwalk ? 2 : (aligned ? 1 : 0));
+		li.lds_bytes_per_workgroup = L.lds_bytes + vfgs::kParamBytes;
+		vfgs::describe_launch(li.kernel, sizeof li.kernel, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide);
 		g_last_launch_valid = true;
 	}
 	return 0;

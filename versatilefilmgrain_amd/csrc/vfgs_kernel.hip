@@ -10,23 +10,21 @@
 // (block_row * blocks_per_line + block), F is the 3-tap filter at block edges, and the
 // window of the block row above feeds the 2-line overlap.
 //
-// Work decomposition (DESIGN.md "kernel"):
-//   * every lane moves 16 bytes per access (8 samples at 10 bit, 16 samples at 8 bit), one
-//     wave access = one contiguous <= 1 KiB "segment" of a row, 4 segments = one "tile";
-//   * the unit grid is shifted left of the block grid by half a block, so every block edge --
-//     the only place where a sample depends on its horizontal neighbours -- lies inside a lane
-//     or between the two lanes of a pair: no halo, no inter-wave exchange, in place is race free;
-//   * a WAVEFRONT owns one tile and walks kRowsPerWave rows of ONE block row down that tile: the
-//     lane geometry and the block parameters (LFSR window -> sign, pattern offsets) are computed
-//     once and reused for every row; while a segment is being computed the same registers of the
-//     segment after next are already being refilled ("rolling prefetch": the registers of a
-//     segment are reloaded with the next row right after its store);
-//   * a WORKGROUP of 4 waves covers all tiles of a few consecutive rows (full rows, contiguous in
-//     memory), is NOT persistent and copies only its plane's banks + LUTs to LDS; workgroups are
-//     numbered in memory order, so the chip sweeps the frames front to back with a compact window
-//     and the hardware dispatcher balances the load;
-//   * a component whose pattern LUT selects one slot for every intensity is served from a packed
-//     one-byte-per-sample bank (ONEY / ONEC kernels, vfgs_layout.h).
+// Work decomposition ("row walk"; one kernel family since round 4):
+//   * every lane moves 16 bytes per access (8 samples at 10 bit, 16 samples at 8 bit), one wave access = one line-aligned
+//     1 KiB "position" of a row;
+//   * the lanes COMPUTE bytes shifted left of the block grid by half a block, so every block edge -- the only place where a
+//     sample depends on its horizontal neighbours -- lies inside a lane or between the two lanes of a pair: no halo, no
+//     inter-wave exchange, in place is race free; the shift between what a lane moves and what it computes is a rotation by
+//     one lane in registers (DPP);
+//   * a WAVEFRONT owns whole rows and streams them through a ring of four register sets; a WORKGROUP of 4 waves covers a few
+//     consecutive rows of ONE block row, is NOT persistent, copies only its plane's banks + LUTs to LDS and computes the block
+//     parameters of its block row (LFSR window -> sign, pattern offsets) once, into LDS; workgroups are numbered in memory
+//     order, so the chip sweeps the frames front to back and the hardware dispatcher balances the load;
+//   * a component whose pattern LUT selects one slot for every intensity is served from a packed one-byte-per-sample bank
+//     (ONEY / ONEC kernels, vfgs_layout.h);
+//   * rows of more than 512 grain blocks (8192 luma samples) are walked in parts of 512 blocks, the parameter table refilled
+//     between the parts; the 8-bit output of a 10-bit path (yuv.c:216-258) is a narrowing in the store (OUT8 kernels).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -345,18 +343,11 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	}
 }
 
-// ---------------------------------------------------------------------------------------
-// One workgroup's share of one plane.
-//
-// Partly valid lanes.  Where a lane is not half a block (every plane type but PAIR) the first lane of a row
-// begins before the row and the last one ends behind it.  Such a lane LOADS the 16 bytes at its offset clamped
-// into the row (all bytes it reads belong to the row; the surplus is its neighbour's data and is ignored), then
-// rotates its dwords into place; it STORES only its own dwords, with dword (or 8-byte) stores that every
-// segment issues and that are switched off (kOOB) in all other lanes.  The instruction stream therefore does
-// not depend on where those lanes are -- which is what lets the compiler count outstanding refills (a
-// wave-uniform branch around a memory instruction makes it wait for everything instead).
 
-template <int AUX = VFGS_LDAUX>
+// ---------------------------------------------------------------------------------------
+// memory helpers
+
+template <int AUX>
 __device__ __forceinline__ void load_seg(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, uint32_t (&w)[4])
 {
 	const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
@@ -374,420 +365,50 @@ __device__ __forceinline__ void store_data_hazard()
 	__builtin_amdgcn_sched_barrier(0);
 }
 
-template <int AUX = VFGS_STAUX>
-__device__ __forceinline__ void store_b128(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, const uint32_t (&w)[4])
+// one unit of the destination: 16 bytes, or 8 where a 10-bit source is narrowed to 8 bit (DW = 2)
+template <int DW, int AUX>
+__device__ __forceinline__ void store_unit(__amdgpu_buffer_rsrc_t rs, uint32_t voff, const uint32_t (&w)[DW])
 {
-	const u32x4 t = {w[0], w[1], w[2], w[3]};
-	__builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, AUX);
-	store_data_hazard();
-}
-
-// the first / last N dwords of a unit (aligned mode: the part of a unit that belongs to the neighbouring tile's wave)
-template <int N, int AUX>
-__device__ __forceinline__ void load_dwords(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, uint32_t (&w)[4])
-{
-	if (N == 4) { const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX); w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w; }
-	else if (N == 2) { const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX); w[0] = t.x; w[1] = t.y; }
-	else w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX);
-}
-
-template <int N, int AUX>
-__device__ __forceinline__ void store_dwords(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, const uint32_t* w)
-{
-	if (N == 4) { const u32x4 t = {w[0], w[1], w[2], w[3]}; __builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, soff, AUX); store_data_hazard(); }
-	else if (N == 3) { const u32x3 t = {w[0], w[1], w[2]}; __builtin_amdgcn_raw_buffer_store_b96(t, rs, voff, soff, AUX); store_data_hazard(); }
-	else if (N == 2) { const u32x2 t = {w[0], w[1]}; __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, AUX); }
-	else if (N == 1) __builtin_amdgcn_raw_buffer_store_b32(w[0], rs, voff, soff, AUX);
-}
-
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, bool OUT8, int IMG_BYTES, bool ONE, bool AL, int NEG>
-__device__ __forceinline__ void run_plane(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, int r,
-                                          const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
-{
-	constexpr int NS = DEPTH == 8 ? 16 : 8;
-	constexpr int SZ = DEPTH > 8 ? 2 : 1;
-	using M = LaneMap<NS, BW>;
-	constexpr int NR = M::NR;
-	constexpr int RPB = 16 / SUBY;                       // rows of this plane per block row
-	constexpr int NEF = M::PAIR ? 1 : M::NE;
-	constexpr bool PARTIAL = !AL && !M::PAIR;   // rows of this plane type begin and end with a partly valid lane
-	constexpr int K = M::SHIFT * SZ / 4;                 // aligned mode: dwords of a lane that lie in the memory unit before the lane's own
-	constexpr int LDA = AL ? VFGS_LDAUX_ALIGNED : VFGS_LDAUX, STA = AL ? VFGS_STAUX_ALIGNED : VFGS_STAUX;
-	static_assert(!(AL && OUT8), "the narrowed destination keeps the shifted accesses");
-	constexpr bool HALVES = !(NS == 16 && BW == 8);      // ... whose valid part is one 8-byte half (else: 1 or 3 dwords)
-	const int pt = comp ? 1 : 0;
-
-	// ---- the workgroup's place: block row group, part of the block row, column group; the wave's place inside it.
-	// All wave-uniform; readfirstlane tells the compiler (runtime divisions run on the vector ALU), so that row offsets
-	// and descriptors stay in SGPRs instead of waterfall loops around every buffer instruction.
-	auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-	// (tiles_w, ppb, splits are powers of two -- shifts; only a picture wider than kWavesPerWG tiles has column groups)
-	int colgroup = 0;
-	if (pd.colgroups > 1) { colgroup = r % pd.colgroups; r /= pd.colgroups; }
-	const int split = r & (pd.splits - 1);
-	const int bgroup = r >> pd.lsplits;
-	const int tile = uni(colgroup * pd.tiles_w + (wave & (pd.tiles_w - 1)));
-	const int q = wave >> pd.ltiles_w;
-	const int ph = q & (pd.ppb - 1);
-	const int kbr = uni(bgroup * pd.bpw + (q >> pd.lppb));   // block row inside the stripe
-	const int Rabs = (a.y0 >> 4) + kbr;                  // absolute block row
-	const int row_first = (a.y0 + SUBY - 1) / SUBY;      // first row of the stripe in this plane; the plane pointers address row y0 / SUBY
-	const int prow0 = a.y0 / SUBY;
-	const bool active = (tile < pd.tiles) && (kbr < a.nbrows);
-	// rows of this block row that belong to the stripe: [alo, ahi); mine: base + stp * k, k in [k0, k1)
-	const int alo = max(row_first, Rabs * RPB), ahi = min(row_first + pd.nrows, (Rabs + 1) * RPB);
-#if VFGS_SPLIT_INTERLEAVE
-	// the parts of a block row are interleaved: the workgroups of one block row, dispatched back to back, sweep it together
-	const int lstp = pd.lppb + pd.lsplits, stp = 1 << lstp;
-	const int base = uni(Rabs * RPB + (split << pd.lppb) + ph);
-#else
-	const int lstp = pd.lppb, stp = pd.ppb;
-	const int base = uni(Rabs * RPB + split * (RPB >> pd.lsplits) + ph);
-#endif
-	const int nk = (RPB >> pd.lsplits) >> pd.lppb;
-	int k0 = max(0, alo - base + stp - 1) >> lstp, k1 = min(nk, (max(0, ahi - base) + stp - 1) >> lstp);
-	if (!active) k1 = k0 = 0;
-	k0 = uni(k0); k1 = uni(k1);
-
-	// ---- lane geometry of the 4 segments (once per wave) -----------------------------------------
-	const uint8_t* sbase = a.src[comp] + (uint64_t)f * pd.fpitch;
-	const __amdgpu_buffer_rsrc_t drs = make_rsrc(a.dst[comp] + (uint64_t)f * pd.dfpitch, pd.dextent);
-	const __amdgpu_buffer_rsrc_t strs = make_rsrc((const uint8_t*)a.stream, a.stream_bytes);
-	const int last = a.nblk - 1;
-	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(kbr * a.nblk);
-	const uint32_t up_bit = (kbr > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
-	const bool any_up = (Rabs > 0) && ((base + stp * k0 - Rabs * RPB) * SUBY <= 1);   // my first row is an overlap line (vfgs_hw.c:175,180)
-
-	uint32_t vo[4];                    // byte offset inside a row of the 16 bytes the lane LOADS, or kOOB
-	bool fullm[4];                     // the lane lies completely inside the row: it stores its 16 bytes at vo
-	bool anypart[4];                   // the segment holds a partly valid lane (wave-uniform)
-	bool edge_on[4][NEF];
-	bool first = false;
-	int blk[4][NR];                    // blocks of the lane's runs, clamped to the row
-#pragma unroll
-	for (int g = 0; g < 4; g++)
+	if constexpr (DW == 4)
 	{
-		const int seg = tile * kSegsPerTile + g;
-		const int p = seg * pd.upt + lane;                                 // lane position along the row
-		const bool sok = (seg < pd.segs) && (lane < pd.upt);
-		const int x = p * 16 - M::SHIFT * SZ;                              // first byte of the lane in the row
-		const bool full = AL ? (sok && p * 16 + 16 <= (int)pd.rowbytes) : (sok && x >= 0 && x + 16 <= (int)pd.rowbytes);
-		const bool part = PARTIAL && sok && !full && x + 16 > 0 && x < (int)pd.rowbytes;
-		fullm[g] = full;
-		anypart[g] = PARTIAL && __builtin_amdgcn_ballot_w64(part) != 0;
-		// aligned mode: the lane MOVES memory unit p (bytes [16p, 16p + 16) of the row) and COMPUTES bytes [x, x + 16)
-		vo[g] = full ? (uint32_t)(AL ? p * 16 : x) : (part ? (uint32_t)min(max(x, 0), (int)pd.rowbytes - 16) : kOOB);
-		if (M::PAIR)
-		{
-			const int ju = p - 1;                                          // 8-sample unit of the row
-			first = !(ju & 1);
-			blk[g][0] = min(max(ju >> 1, 0), last);
-			const int jl = first ? ju - 1 : ju;                            // left unit of this lane pair
-			edge_on[g][0] = sok && (jl >= 0) && (jl + 1 < 2 * a.nblk);
-		}
-		else
-		{
-			const int b0 = p * M::BPL - 1;                                 // block of run 0
-#pragma unroll
-			for (int rr = 0; rr < NR; rr++) blk[g][rr] = min(max(b0 + rr, 0), last);
-#pragma unroll
-			for (int ed = 0; ed < M::NE; ed++) edge_on[g][ed] = sok && (b0 + ed >= 0) && (b0 + ed + 1 <= last);
-		}
+		const u32x4 t = {w[0], w[1], w[2], w[3]};
+		__builtin_amdgcn_raw_buffer_store_b128(t, rs, voff, 0, AUX);
+		store_data_hazard();
 	}
-	// a partly valid lane, after its load from the clamped offset: move its dwords to where they belong
-	auto rotate_partial = [&](int g, uint32_t (&t)[4]) {
-		const int seg = tile * kSegsPerTile + g;
-		int x = (seg * pd.upt + lane) * 16 - M::SHIFT * SZ;
-		asm volatile("" : "+v"(x));       // opaque to the optimiser: keeps this rarely needed arithmetic out of the registers of the row loop
-		const bool part = !fullm[g] && vo[g] != kOOB;
-		if (HALVES)
-		{   // the lane holds bytes [x', x' + 16) with x' = x +- 8: its own half sits in the other half of the registers
-			const uint32_t t0 = t[0], t1 = t[1];
-			t[0] = part ? t[2] : t0; t[1] = part ? t[3] : t1;
-			t[2] = part ? t0 : t[2]; t[3] = part ? t1 : t[3];
-		}
-		else
-		{   // x' - x = +4 (first lane), -4 or -12 (last lane): rotate by one dword, and by two more where it is -12
-			const int kk = ((x - (int)vo[g]) >> 2) & 3;                     // t[d] belongs at d - kk
-			const bool r1 = part && (kk & 1), r2 = part && (kk & 2);
-			uint32_t u[4];
-#pragma unroll
-			for (int d = 0; d < 4; d++) u[d] = r1 ? t[(d + 1) & 3] : t[d];
-#pragma unroll
-			for (int d = 0; d < 4; d++) t[d] = r2 ? u[(d + 2) & 3] : u[d];
-		}
-	};
-	// ... and its stores: only the dwords inside the row (all other lanes: kOOB)
-	auto store_partial = [&](int g, uint32_t soff, const uint32_t (&t)[4]) {
-		const int seg = tile * kSegsPerTile + g;
-		int x = (seg * pd.upt + lane) * 16 - M::SHIFT * SZ;
-		asm volatile("" : "+v"(x));
-		const bool part = !fullm[g] && vo[g] != kOOB;
-		if (!OUT8)
-		{
-			if (HALVES)
-			{   // the valid half: the upper one of the first lane (x < 0), the lower one of the last lane
-				const bool upper = x < 0;
-				const u32x2 d = {upper ? t[2] : t[0], upper ? t[3] : t[1]};
-				__builtin_amdgcn_raw_buffer_store_b64(d, drs, part ? (uint32_t)(upper ? 0 : x) : kOOB, soff, VFGS_STAUX);
-			}
-			else
-			{
-#pragma unroll
-				for (int d = 0; d < 4; d++)
-				{
-					const bool in = part && x + 4 * d >= 0 && x + 4 * d + 4 <= (int)pd.rowbytes;
-					__builtin_amdgcn_raw_buffer_store_b32(t[d], drs, in ? (uint32_t)(x + 4 * d) : kOOB, soff, VFGS_STAUX);
-				}
-			}
-		}
-		else
-		{   // narrowed destination: 2 dwords per lane, the valid one is the upper one of the first lane, the lower one of the last lane
-			const bool upper = x < 0;
-			__builtin_amdgcn_raw_buffer_store_b32(upper ? t[1] : t[0], drs, part ? (uint32_t)(upper ? 0 : x / 2) : kOOB, soff, VFGS_STAUX);
-		}
-	};
-
-	// ---- in flight together: the table image, the LFSR windows of my blocks, the first row's samples -----
-	// In THIS order: a wave's loads return in the order they were issued, so the table image and the LFSR words (L2 hits,
-	// ~1 us under load) must not queue behind the first row's samples (HBM, several us under load) -- the workgroup's
-	// barrier and the block parameters are then done by the time the samples arrive (measured with s_memrealtime marks:
-	// the barrier was passed 5.8 us after wave start with the samples first).  The instruction stream is
-	// fixed (clamped addresses and zero-record descriptors instead of branches) so that the waits can be counted.
-	constexpr int STEP = kWavesPerWG * 64 * 16;
-	constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
-	static_assert(IMG_BYTES % 16 == 0, "table image in whole 16-byte units");
-	u32x4 tmp[NIT];
+	else
 	{
-		const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.tables + img_off, IMG_BYTES);
-#pragma unroll
-		for (int it = 0; it < NIT; it++)      // threads beyond the image re-read (and re-write) its last unit
-			tmp[it] = __builtin_amdgcn_raw_buffer_load_b128(irs, min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16)), 0, 0);
-	}
-	u32x2 wcur[4][NR], wup[4][NR];
-	{
-		const __amdgpu_buffer_rsrc_t strs_up = make_rsrc((const uint8_t*)a.stream, any_up ? a.stream_bytes : 0);
-#pragma unroll
-		for (int g = 0; g < 4; g++)
-#pragma unroll
-			for (int rr = 0; rr < NR; rr++)
-			{
-				wcur[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs, ((cur_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
-				wup[g][rr] = __builtin_amdgcn_raw_buffer_load_b64(strs_up, ((up_bit + (uint32_t)blk[g][rr]) >> 5) * 4, 0, 0);
-			}
-	}
-	// aligned mode: the last K dwords of the unit before the tile are this wave's (lane 0 of segment 0 computes them), the
-	// last K dwords of the tile's last unit are the next wave's
-	uint32_t pre[4] = {0, 0, 0, 0};
-	const uint32_t preoff = (AL && lane == 0 && tile > 0 && tile * kSegsPerTile < pd.segs) ? (uint32_t)(tile * (kSegsPerTile * kMaxUnits * 16) - K * 4) : kOOB;
-	const uint32_t vos3 = (AL && lane == 63) ? kOOB : vo[3];
-	const uint32_t tailoff = (AL && lane == 63) ? vo[3] : kOOB;
-	uint32_t rowb = (uint32_t)uni((base + stp * k0 - prow0) * (int)pd.pitch), drowb = (uint32_t)uni((base + stp * k0 - prow0) * (int)pd.dpitch);
-	const uint32_t rstep = (uint32_t)stp * pd.pitch, drstep = (uint32_t)stp * pd.dpitch;
-	uint32_t w[4][4];
-	{
-		const __amdgpu_buffer_rsrc_t frs = make_rsrc(sbase, (k0 < k1) ? pd.extent : 0);
-#pragma unroll
-		for (int g = 0; g < 4; g++) load_seg<LDA>(frs, vo[g], rowb, w[g]);
-		if (AL) load_dwords<K, LDA>(frs, preoff, rowb, pre);
-	}
-#pragma unroll
-	for (int it = 0; it < NIT; it++)
-		*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
-	__syncthreads();
-	if (k0 >= k1)
-		return;
-
-	// ---- block parameters (once per wave) ------------------------------------------------------------
-	const int fsx = comp == 0 ? 0 : (comp == 1 ? 10 : 20);
-	const int fsy = comp == 0 ? 14 : (comp == 1 ? 24 : 4);
-	const int fsb = comp == 0 ? 31 : (comp == 1 ? 2 : 15);
-	const uint32_t lutb = lut_off * 0x10001u;
-	const uint32_t lo2 = a.lo2[pt], hi2 = a.hi2[pt];
-	const uint32_t pairoff = M::PAIR ? (first ? 0u : 8u * (ONE ? 1 : kSlots)) : 0u;
-	RunParam<NR> rp[4];
-#pragma unroll
-	for (int g = 0; g < 4; g++)
-#pragma unroll
-		for (int rr = 0; rr < NR; rr++)
-		{
-			const uint32_t v = __builtin_amdgcn_alignbit(wcur[g][rr].y, wcur[g][rr].x, (cur_bit + (uint32_t)blk[g][rr]) & 31);
-			bool neg;
-			const uint32_t ad = block_param<SUBX, SUBY, RS, ONE>(v, bank_off, fsx, fsy, fsb, &neg) + pairoff + ((ONE && neg) ? (uint32_t)NEG : 0u);
-			rp[g].pa[rr] = ad | (neg ? 0x80000000u : 0u);
-		}
-
-	// ---- rows ---------------------------------------------------------------------------------------
-	// (all four segments always run -- lanes of segments beyond the row carry kOOB -- so that the instruction stream is
-	// fixed and the compiler can count the outstanding refills instead of waiting for all of them)
-	auto row = [&](auto overlap, const int k, const RunParam<NR> (&up)[4], const int wc_, const int wu_) {
-		constexpr bool OV = decltype(overlap)::value;
-		const int j = base + stp * k - Rabs * RPB;                        // row inside the block row
-		const uint32_t rowoff = (uint32_t)j * RS, uprowoff = (uint32_t)(RPB + j) * RS;
-		// the refill of the row after my last one goes through a descriptor with zero records: the hardware
-		// drops it, the instruction stream (and the compiler's vmcnt counting) stays the same
-		const __amdgpu_buffer_rsrc_t nrs = make_rsrc(sbase, (k + 1 < k1) ? pd.extent : 0);
-#pragma unroll
-		for (int g = 0; g < 4; g++)
-		{
-#if !VFGS_PREFETCH
-			load_seg(make_rsrc(sbase, pd.extent), vo[g], rowb, w[g]);
-#endif
-			uint32_t t[4] = {w[g][0], w[g][1], w[g][2], w[g][3]};
-			if (PARTIAL && anypart[g]) rotate_partial(g, t);
-			grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2, NEG>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
-			if (OUT8)
-			{
-				uint32_t n[4];
-#pragma unroll
-				for (int d = 0; d < 4; d++)   // yuv_to_8bit (yuv.c:216-258): out8 = (v + 2) >> 2; both halves <= 1022: no carry across the halves
-					n[d] = ((t[d] + 0x00020002u) >> 2) & 0x00ff00ffu;
-				uint32_t o[4] = {__builtin_amdgcn_perm(n[1], n[0], 0x06040200), __builtin_amdgcn_perm(n[3], n[2], 0x06040200), 0, 0};
-				const u32x2 d2 = {o[0], o[1]};
-				__builtin_amdgcn_raw_buffer_store_b64(d2, drs, fullm[g] ? vo[g] >> 1 : kOOB, drowb, VFGS_STAUX);
-				if (PARTIAL) store_partial(g, drowb, o);
-			}
-			else
-			{
-				store_b128(drs, fullm[g] ? vo[g] : kOOB, drowb, t);
-				if (PARTIAL) store_partial(g, drowb, t);
-			}
-#if VFGS_PREFETCH
-			load_seg(nrs, vo[g], rowb + rstep, w[g]);
-#endif
-#if VFGS_SCHED_FENCE
-			// keep the refill where it is: with registers to spare hipcc's scheduler otherwise computes all four segments
-			// first and issues the four stores and the four refills together at the end of the row -- every row would then
-			// start with a full memory latency
-			__builtin_amdgcn_sched_barrier(0);
-#endif
-		}
-		rowb += rstep;
-		drowb += drstep;
-	};
-
-	// Aligned mode.  The memory side moves whole aligned units (line-aligned 1 KiB wave accesses, nontemporal: DESIGN.md 4);
-	// the computation keeps the half-block shifted lanes.  A lane's 4 dwords are the last K dwords of the unit of the lane
-	// BEFORE it (DPP wave_shr:1; lane 0 takes them from lane 63 of the previous segment through SGPRs, or from the unit in
-	// front of the tile) and the first 4 - K of its own; results go back the same way, so the store of a segment waits for
-	// lane 0 of the NEXT segment.  The registers of a segment are refilled as soon as the lanes have been assembled.
-	auto row_al = [&](auto overlap, const int k, const RunParam<NR> (&up)[4], const int wc_, const int wu_) {
-		constexpr bool OV = decltype(overlap)::value;
-		const int j = base + stp * k - Rabs * RPB;
-		const uint32_t rowoff = (uint32_t)j * RS, uprowoff = (uint32_t)(RPB + j) * RS;
-		const __amdgpu_buffer_rsrc_t nrs = make_rsrc(sbase, (k + 1 < k1) ? pd.extent : 0);
-		const bool is0 = lane == 0, is63 = lane == 63;
-#if VFGS_LANE_SHIFT_DPP
-		auto lane_up = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); };    // wave_shr:1
-		auto lane_down = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); };  // wave_shl:1
-#else
-		const int a_prev = ((lane - 1) & 63) * 4, a_next = ((lane + 1) & 63) * 4;
-		auto lane_up = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(a_prev, (int)v); };
-		auto lane_down = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(a_next, (int)v); };
-#endif
-		uint32_t carry[4] = {0, 0, 0, 0};      // wave-uniform: the last K dwords of lane 63 of the previous segment
-		uint32_t outp[4] = {0, 0, 0, 0};       // the previous segment's units, complete but for lane 63
-#pragma unroll
-		for (int g = 0; g < 4; g++)
-		{
-			uint32_t t[4];
-#pragma unroll
-			for (int d = 0; d < K; d++)
-			{
-				const uint32_t sh = lane_up(w[g][4 - K + d]);   // lane l <- lane l - 1
-				t[d] = is0 ? (g == 0 ? pre[d] : carry[d]) : sh;
-			}
-#pragma unroll
-			for (int d = 0; d < K; d++) carry[d] = (uint32_t)__builtin_amdgcn_readlane((int)w[g][4 - K + d], 63);
-#pragma unroll
-			for (int d = K; d < 4; d++) t[d] = w[g][d - K];
-			load_seg<LDA>(nrs, vo[g], rowb + rstep, w[g]);
-			if (g == 0) load_dwords<K, LDA>(nrs, preoff, rowb + rstep, pre);
-			grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2, NEG>(lds, t, rp[g], up[g], lutb, rowoff, uprowoff, wc_, wu_, edge_on[g], first, lo2, hi2);
-			if (g == 0)
-			{
-				store_dwords<K, STA>(drs, preoff, drowb, t);               // lane 0: the tail of the unit in front of the tile
-			}
-			else
-			{
-#pragma unroll
-				for (int d = 0; d < K; d++)
-				{
-					const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)t[d], 0);
-					outp[4 - K + d] = is63 ? l0 : outp[4 - K + d];
-				}
-				store_b128<STA>(drs, vo[g - 1], drowb, outp);
-			}
-#pragma unroll
-			for (int d = K; d < 4; d++) outp[d - K] = t[d];
-#pragma unroll
-			for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(t[d]);   // lane l <- lane l + 1
-#if VFGS_SCHED_FENCE
-			__builtin_amdgcn_sched_barrier(0);
-#endif
-		}
-		store_b128<STA>(drs, vos3, drowb, outp);
-		if (K < 4) store_dwords<4 - K, STA>(drs, tailoff, drowb, outp);       // lane 63: the head of the tile's last unit
-		rowb += rstep;
-		drowb += drstep;
-	};
-	auto row_any = [&](auto overlap, const int k, const RunParam<NR> (&up)[4], const int wc_, const int wu_) {
-		if constexpr (AL) row_al(overlap, k, up, wc_, wu_); else row(overlap, k, up, wc_, wu_);
-	};
-
-	int k = k0;
-	if (any_up)
-	{
-		// the lines j = 0, 1 of a block row (luma lines; a vertically subsampled plane has only j = 0) blend in
-		// the block above (vfgs_hw.c:173-188, 223-229); they come first in my walk
-		RunParam<NR> up[4];
-#pragma unroll
-		for (int g = 0; g < 4; g++)
-#pragma unroll
-			for (int rr = 0; rr < NR; rr++)
-			{
-				const uint32_t v = __builtin_amdgcn_alignbit(wup[g][rr].y, wup[g][rr].x, (up_bit + (uint32_t)blk[g][rr]) & 31);
-				bool neg;
-				const uint32_t ad = block_param<SUBX, SUBY, RS, ONE>(v, bank_off, fsx, fsy, fsb, &neg) + pairoff;
-				up[g].pa[rr] = ad | (neg ? 0x80000000u : 0u);
-			}
-		for (; k < k1; k++)
-		{
-			const int jrow = (base + stp * k - Rabs * RPB) * SUBY;
-			if (jrow > 1) break;
-			const int wc_ = jrow == 0 ? (SUBY > 1 ? 20 : 12) : 24, wu_ = jrow == 0 ? (SUBY > 1 ? 20 : 24) : 12;
-			row_any(std::true_type(), k, up, wc_, wu_);
-		}
-	}
-	{
-		RunParam<NR> none[4] = {};
-		for (; k < k1; k++)
-			row_any(std::false_type(), k, none, 0, 0);
+		const u32x2 t = {w[0], w[1]};
+		__builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, 0, AUX);
 	}
 }
 
 // ---------------------------------------------------------------------------------------
-// Row walk: the product path for pictures whose rows hold at most kTileBlocks grain blocks (8192 luma samples).
+// Row walk: one workgroup's share of one plane.
 //
-// tools/skeleton2.hip (profiles/r03_skeleton2_*.log) priced what the tiled kernels above pay besides their bytes: every
-// vector-memory INSTRUCTION queues for the CU's saturated memory pipeline, and a 4 KiB tile costs 11 of them where 8 move
-// data (the aligned kernels' narrow accesses at both tile edges), plus 8 LFSR loads per wave: 0.73 -> 0.67 of 8 TB/s.
+// tools/skeleton2.hip (profiles/r03_skeleton2_*.log) priced what round 2's tiled kernels paid besides their bytes: every
+// vector-memory INSTRUCTION queues for the CU's saturated memory pipeline, and a 4 KiB tile cost 11 of them where 8 move
+// data (narrow accesses at both tile edges), plus 8 LFSR loads per wave: 0.73 -> 0.67 of 8 TB/s.
 // Here a wave owns whole ROWS instead of a tile of several rows:
-//   * a workgroup = 4 waves = 4 x rw_rpw rows of ONE block row (wave w: rows w, w + 4, ...; the same ~60 KB and the same
-//     table image per workgroup as before); a wave streams its row segment by segment (64 aligned 16-byte units each)
-//     through a ring of four register sets -- the refill of a set is the segment four steps ahead, across row ends --
-//     so a row costs one load and one store per KiB and nothing else: no tile edges, no narrow accesses;
-//   * the block parameters of the row's <= 512 blocks (this block row's LFSR registers and, for the workgroup that holds
-//     the overlap lines, those of the block row above) are computed ONCE per workgroup, one or two blocks per thread, and
-//     kept in LDS behind the table image; a lane reads its 1-3 entries per segment (the tiled kernels hold 4 segments x
-//     1-3 runs x 2 in registers: the 8-bit 4:2:x kernels spilled on that);
-//   * lanes compute the half-block shifted bytes as in the aligned kernels: rotation by one lane with DPP wave_shr / wave_shl,
-//     the hand-over between consecutive segments of a row with wave_ror / wave_rol (the previous segment's lane 63 waits in
-//     lane 0 of a register and enters as the `old` operand of the shift: no v_readlane, no scalar round trip); a segment's
-//     units are stored one step later, once lane 0 of the next segment has delivered the last dwords of its lane 63;
-//   * row bases and segment offsets live in the buffer descriptor (base, num_records = bytes of the row left), so the
-//     hardware range check covers every access of every lane: lanes behind the row's end load 0 and store nothing.
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE, int NEG, int NARROW>
+//   * a workgroup = 4 waves = 4 x rw_rpw rows of ONE block row (wave w: rows w, w + 4, ...); a wave streams its row position
+//     by position (64 aligned 16-byte units each) through a ring of four register sets -- the refill of a set is the position
+//     four steps ahead, across row ends -- so a row costs one load and one store per KiB and nothing else;
+//   * the block parameters of the row's blocks (this block row's LFSR registers and, for the workgroup that holds the overlap
+//     lines, those of the block row above) are computed ONCE per workgroup, one or two blocks per thread, and kept in LDS
+//     behind the table image; a lane reads its 1-3 entries per position;
+//   * lanes compute the half-block shifted bytes: rotation by one lane with DPP wave_shr / wave_shl, the hand-over between
+//     consecutive positions of a row with wave_ror / wave_rol (the previous position's lane 63 waits in lane 0 of a register
+//     and enters as the `old` operand of the shift: no v_readlane, no scalar round trip); a position's units are stored one
+//     step later, once lane 0 of the next position has delivered the last dwords of its lane 63;
+//   * row bases and position offsets live in the buffer descriptor (base, num_records = bytes of the row left), so the
+//     hardware range check covers every access of every lane: lanes behind the row's end load 0 and store nothing
+//     (8-bit 4:2:x rows of an odd number of blocks end in HALF a unit: the check works per dword);
+//   * rows of more than kTileBlocks blocks (WIDE kernels, general form of the table image only): the table holds one PART of
+//     the row (kTileBlocks blocks) at a time; all waves walk part 0 of their row, the workgroup refills the table for part 1
+//     between two barriers, and so on -- the ring of register sets simply runs on (the host gives such workgroups one row per wave);
+//   * OUT8 (10-bit source, 8-bit destination, yuv.c:216-258): out8 = (v + 2) >> 2 is applied to a lane's results, which
+//     halves them (DW = 2 dwords per unit); everything behind the computation -- rotation back, stores, descriptors -- works
+//     on those halves with the destination's own pitches.
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE, int NEG, int NARROW, bool OUT8, bool WIDE>
 __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, const int r,
                                              const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
 {
@@ -798,9 +419,15 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	constexpr int RPB = 16 / SUBY;                       // rows of this plane per block row
 	constexpr int NEF = M::PAIR ? 1 : M::NE;
 	constexpr int K = M::SHIFT * SZ / 4;                 // dwords of a lane that lie in the memory unit before the lane's own
+	constexpr int DW = OUT8 ? 2 : 4;                     // dwords of a unit in the destination ...
+	constexpr int KD = OUT8 ? K / 2 : K;                 // ... and how many of a lane's result dwords belong to the unit before its own
+	static_assert(!OUT8 || (DEPTH == 10 && K % 2 == 0), "the narrowed destination exists for 10-bit sources");
 	constexpr int LDA = VFGS_LDAUX_ALIGNED, STA = VFGS_STAUX_ALIGNED;
 	constexpr int LPB = M::PAIR ? 1 : M::BPL;            // blocks per lane step (PAIR: half a block, see idx0 below)
-	constexpr int BPS = M::PAIR ? 32 : 64 * M::BPL;      // grain blocks a segment advances by
+	constexpr int BPS = M::PAIR ? 32 : 64 * M::BPL;      // grain blocks a position advances by
+	constexpr int NU = 4;                                // positions per group = register sets of the ring
+	constexpr int GPP = kTileBlocks / (NU * BPS);        // groups per part of a row (a part = kTileBlocks blocks = one parameter table)
+	static_assert(GPP * NU * BPS == kTileBlocks, "a part is a whole number of groups");
 	constexpr uint32_t PT_CUR = IMG_BYTES, PT_UP = IMG_BYTES + kParamTableBytes;
 	static_assert(IMG_BYTES % 16 == 0, "table image in whole 16-byte units");
 	const int pt = comp ? 1 : 0;
@@ -831,7 +458,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	const uint32_t cur_bit = a.cur_bit0 + (uint32_t)f * a.frame_bit_step + (uint32_t)(kbr * a.nblk);
 	const uint32_t up_bit = (kbr > 0) ? cur_bit - (uint32_t)a.nblk : a.up_bit0 + (uint32_t)f * a.frame_bit_step;
 
-	// ---- in flight together: the table image, the LFSR words of the row's blocks, my first four segments -----------
+	// ---- in flight together: the table image, the LFSR words of the row's blocks, my first four positions ----------
 	// (in this order: a wave's loads return in issue order; fixed instruction stream)
 	constexpr int STEP = kWavesPerWG * 64 * 16;
 	constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
@@ -842,43 +469,75 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 		for (int it = 0; it < NIT; it++)      // threads beyond the image re-read (and re-write) its last unit
 			tmp[it] = __builtin_amdgcn_raw_buffer_load_b128(irs, min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16)), 0, 0);
 	}
-	// parameter table entry e = block e - 1 (clamped into the row): thread t fills entries t, t + 256, ...
+	// parameter table of the part that begins at block B0: entry e = block B0 + e - 1 (clamped into the row); thread t fills
+	// entries t, t + 256, ...
 	constexpr int NPE = (kParamEntries + kWavesPerWG * 64 - 1) / (kWavesPerWG * 64);
-	u32x2 wc[NPE], wu[NPE];
-	{
-		const __amdgpu_buffer_rsrc_t strs = make_rsrc((const uint8_t*)a.stream, a.stream_bytes);
-		const __amdgpu_buffer_rsrc_t strs_up = make_rsrc((const uint8_t*)a.stream, wg_up ? a.stream_bytes : 0);
+	const __amdgpu_buffer_rsrc_t strs = make_rsrc((const uint8_t*)a.stream, a.stream_bytes);
+	const __amdgpu_buffer_rsrc_t strs_up = make_rsrc((const uint8_t*)a.stream, wg_up ? a.stream_bytes : 0);
+	auto param_loads = [&](const int B0, u32x2 (&wc)[NPE], u32x2 (&wu)[NPE]) {
 #pragma unroll
 		for (int i = 0; i < NPE; i++)
 		{
 			const int e = (int)threadIdx.x + i * kWavesPerWG * 64;
-			const uint32_t blk = (uint32_t)min(max(e - 1, 0), last);
-			const bool need = e < a.nblk + 4 && e < kParamEntries;
+			const uint32_t blk = (uint32_t)min(max(B0 + e - 1, 0), last);
+			const bool need = e < a.nblk - B0 + 4 && e < kParamEntries;
 			wc[i] = __builtin_amdgcn_raw_buffer_load_b64(strs, need ? ((cur_bit + blk) >> 5) * 4 : kOOB, 0, 0);
 			wu[i] = __builtin_amdgcn_raw_buffer_load_b64(strs_up, need ? ((up_bit + blk) >> 5) * 4 : kOOB, 0, 0);
 		}
-	}
+	};
+	const int fsx = comp == 0 ? 0 : (comp == 1 ? 10 : 20);
+	const int fsy = comp == 0 ? 14 : (comp == 1 ? 24 : 4);
+	const int fsb = comp == 0 ? 31 : (comp == 1 ? 2 : 15);
+	auto param_table = [&](const int B0, const u32x2 (&wc)[NPE], const u32x2 (&wu)[NPE]) {
+#pragma unroll
+		for (int i = 0; i < NPE; i++)
+		{
+			// (rows of up to 252 blocks -- 2160p and narrower -- need the first round only, 4320p two of the three: a wave-uniform
+			// branch around arithmetic and LDS writes; the LFSR loads stay unconditional, switched off by their offsets, so
+			// that the waits can still be counted)
+			if (i > 0 && i * kWavesPerWG * 64 >= a.nblk - B0 + 4) break;
+			const int e = (int)threadIdx.x + i * kWavesPerWG * 64;
+			const uint32_t blk = (uint32_t)min(max(B0 + e - 1, 0), last);
+			bool neg;
+			const uint32_t vc = __builtin_amdgcn_alignbit(wc[i].y, wc[i].x, (cur_bit + blk) & 31);
+			const uint32_t pc = (block_param<SUBX, SUBY, RS, ONE>(vc, bank_off, fsx, fsy, fsb, &neg) + ((ONE && neg) ? (uint32_t)NEG : 0u)) | (neg ? 0x80000000u : 0u);
+			const uint32_t vu = __builtin_amdgcn_alignbit(wu[i].y, wu[i].x, (up_bit + blk) & 31);
+			const uint32_t pu = block_param<SUBX, SUBY, RS, ONE>(vu, bank_off, fsx, fsy, fsb, &neg) | (neg ? 0x80000000u : 0u);
+			if (e < kParamEntries)
+			{
+				*(uint32_t*)(lds + PT_CUR + e * 4) = pc;
+				*(uint32_t*)(lds + PT_UP + e * 4) = pu;
+			}
+		}
+	};
+	u32x2 wc0[NPE], wu0[NPE];
+	param_loads(0, wc0, wu0);
 	// A row = rw_segs wave accesses ("positions": its units and the one behind them), walked in groups of four: the four
 	// register sets.  One buffer descriptor serves a whole group: base = the first byte of the group, num_records = the
-	// bytes the row has left from there (at most the group's 4 KiB), the segment's 1 KiB step sits in the instruction's
+	// bytes the row has left from there (at most the group's 4 KiB), the position's 1 KiB step sits in the instruction's
 	// immediate offset: the hardware range check switches off exactly the lanes behind the row's end -- and every lane of a
 	// group that does not exist -- and no access of any lane can leave the row.  (Measured on gfx950: a scalar offset
 	// operand IS part of what is checked against num_records, so the row offset has to go into the base.)
 	const int tsegs = pd.rw_segs;
-	constexpr int NU = 4;                          // positions per group = register sets of the ring
 	const int ngroups = (tsegs + NU - 1) / NU;
 	const uint8_t* sbase = a.src[comp] + (uint64_t)f * pd.fpitch;
 	uint8_t* dbase = a.dst[comp] + (uint64_t)f * pd.dfpitch;
 	const uint32_t lane16 = (uint32_t)lane * 16;
-	constexpr uint32_t GB = NU * kMaxUnits * 16;         // bytes of a group
+	const uint32_t laned = (uint32_t)lane * (4 * DW);    // ... in the destination
+	constexpr uint32_t UB = kMaxUnits * 16, UBD = kMaxUnits * 4 * DW;   // bytes of a position, source / destination
+	constexpr uint32_t GB = NU * UB, GBD = NU * UBD;     // bytes of a group
 	auto row_off = [&](int k) { return (uint32_t)((base + RSTR * k - prow0) * (int)pd.pitch); };
+	// (only the narrowed destination has a geometry of its own: otherwise the host passes the source's, and saying so here
+	// saves the scalar registers of a second set of row offsets)
+	auto row_offd = [&](int k) { return OUT8 ? (uint32_t)((base + RSTR * k - prow0) * (int)pd.dpitch) : row_off(k); };
 	auto left = [&](int g) { const uint32_t o = (uint32_t)g * GB; return o < pd.rowbytes ? min(pd.rowbytes - o, GB) : 0u; };
+	auto leftd = [&](int g) { const uint32_t o = (uint32_t)g * GBD, rb = OUT8 ? pd.drowbytes : pd.rowbytes; return o < rb ? min(rb - o, GBD) : 0u; };
 	uint32_t w[NU][4];
 	if constexpr (NARROW == 0)
 	{
 		const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(sbase + (k0 < k1 ? row_off(k0) : 0u), k0 < k1 ? left(0) : 0u);
 #pragma unroll
-		for (int u = 0; u < NU; u++) load_seg<LDA>(rs0, lane16 + u * (kMaxUnits * 16), 0, w[u]);
+		for (int u = 0; u < NU; u++) load_seg<LDA>(rs0, lane16 + u * UB, 0, w[u]);
 	}
 	else
 	{
@@ -888,39 +547,21 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 		{
 			const int k = k0 + u / NARROW;
 			const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(sbase + (k < k1 ? row_off(k) : 0u), k < k1 ? pd.rowbytes : 0u);
-			load_seg<LDA>(rs0, lane16 + (u % NARROW) * (kMaxUnits * 16), 0, w[u]);
+			load_seg<LDA>(rs0, lane16 + (u % NARROW) * UB, 0, w[u]);
 		}
 	}
 #pragma unroll
 	for (int it = 0; it < NIT; it++)
 		*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
 
-	// ---- block parameters of the row (once per workgroup) ----------------------------------------------------------
-	const int fsx = comp == 0 ? 0 : (comp == 1 ? 10 : 20);
-	const int fsy = comp == 0 ? 14 : (comp == 1 ? 24 : 4);
-	const int fsb = comp == 0 ? 31 : (comp == 1 ? 2 : 15);
-#pragma unroll
-	for (int i = 0; i < NPE; i++)
-	{
-		// (rows of up to 252 blocks -- 2160p and narrower -- need the first round only, 4320p two of the three: a wave-uniform
-		// branch around arithmetic and LDS writes; the LFSR loads above stay unconditional, switched off by their offsets, so
-		// that the waits below can still be counted)
-		if (i > 0 && i * kWavesPerWG * 64 >= a.nblk + 4) break;
-		const int e = (int)threadIdx.x + i * kWavesPerWG * 64;
-		const uint32_t blk = (uint32_t)min(max(e - 1, 0), last);
-		bool neg;
-		const uint32_t vc = __builtin_amdgcn_alignbit(wc[i].y, wc[i].x, (cur_bit + blk) & 31);
-		const uint32_t pc = (block_param<SUBX, SUBY, RS, ONE>(vc, bank_off, fsx, fsy, fsb, &neg) + ((ONE && neg) ? (uint32_t)NEG : 0u)) | (neg ? 0x80000000u : 0u);
-		const uint32_t vu = __builtin_amdgcn_alignbit(wu[i].y, wu[i].x, (up_bit + blk) & 31);
-		const uint32_t pu = block_param<SUBX, SUBY, RS, ONE>(vu, bank_off, fsx, fsy, fsb, &neg) | (neg ? 0x80000000u : 0u);
-		if (e < kParamEntries)
-		{
-			*(uint32_t*)(lds + PT_CUR + e * 4) = pc;
-			*(uint32_t*)(lds + PT_UP + e * 4) = pu;
-		}
-	}
+	// ---- block parameters of the row's first part (once per workgroup) ---------------------------------------------
+	param_table(0, wc0, wu0);
 	__syncthreads();
-	if (k0 >= k1)
+	// (WIDE is a kernel of its own: the part loop keeps the LFSR descriptors and a few more values alive through the walk, 5-7
+	// VGPRs and a dozen spilled SGPRs that every picture would pay for -- measured with -Rpass-analysis=kernel-resource-usage)
+	const int nparts = WIDE ? (a.nblk + kTileBlocks - 1) / kTileBlocks : 1;     // (workgroup-uniform: every wave meets the barriers below)
+	static_assert(!(WIDE && NARROW != 0), "rows walked in parts are not narrow");
+	if (k0 >= k1 && nparts == 1)
 		return;
 
 	// ---- per lane constants ------------------------------------------------------------------------------------------
@@ -928,20 +569,37 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	const uint32_t lo2 = a.lo2[pt], hi2 = a.hi2[pt];
 	const bool first = M::PAIR && (lane & 1);                              // PAIR: odd lane positions hold the first half of a block
 	const uint32_t pairoff = M::PAIR ? (first ? 0u : 8u * (ONE ? 1 : kSlots)) : 0u;
-	const uint32_t idx0 = (M::PAIR ? (uint32_t)(lane + 1) >> 1 : (uint32_t)lane * LPB) * 4;   // byte offset of my first entry in segment 0
-	const int cl = M::PAIR ? lane - 1 - (lane & 1) : lane * LPB - 1;       // PAIR: left unit of my lane pair; else: block of run 0 (both for segment 0)
-	constexpr int SSTEP = M::PAIR ? 64 : BPS;                              // what `cl` advances by per segment
+	const uint32_t idx0 = (M::PAIR ? (uint32_t)(lane + 1) >> 1 : (uint32_t)lane * LPB) * 4;   // byte offset of my first entry in position 0 of a part
+	const int cl = M::PAIR ? lane - 1 - (lane & 1) : lane * LPB - 1;       // PAIR: left unit of my lane pair; else: block of run 0 (both for position 0)
+	constexpr int SSTEP = M::PAIR ? 64 : BPS;                              // what `cl` advances by per position
 	// DPP moves by one lane; lanes without a source lane (lane 0 / lane 63) keep `old`; the rotations wrap around
 	auto lane_up = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false); };    // wave_shr:1: lane l <- lane l - 1
 	auto lane_down = [](uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130, 0xf, 0xf, false); };  // wave_shl:1: lane l <- lane l + 1
 	auto rot_up = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x13c, 0xf, 0xf, false); };      // wave_ror:1: lane 0 <- lane 63
 	auto rot_down = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x134, 0xf, 0xf, false); };    // wave_rol:1: lane 63 <- lane 0
+	// a lane's results as they go to memory: the 4 dwords themselves, or narrowed to 8 bit (yuv_to_8bit, yuv.c:216-258:
+	// out8 = (v + 2) >> 2; both halves of a dword are <= 1023 + 2: no carry across them)
+	auto results = [](const uint32_t (&t)[4], uint32_t (&o)[DW]) {
+		if constexpr (OUT8)
+		{
+			uint32_t n[4];
+#pragma unroll
+			for (int d = 0; d < 4; d++) n[d] = ((t[d] + 0x00020002u) >> 2) & 0x00ff00ffu;
+			o[0] = __builtin_amdgcn_perm(n[1], n[0], 0x06040200);
+			o[1] = __builtin_amdgcn_perm(n[3], n[2], 0x06040200);
+		}
+		else
+		{
+#pragma unroll
+			for (int d = 0; d < 4; d++) o[d] = t[d];
+		}
+	};
 
 	// ---- the walk ----------------------------------------------------------------------------------------------------
-	uint32_t carry[4] = {0, 0, 0, 0};      // in lane 0: the last K dwords of lane 63 of the previous segment of the row
-	uint32_t outp[4] = {0, 0, 0, 0};       // the previous segment's units: dwords K.. of its lanes (the first 4 - K dwords of a unit)
-	uint32_t tp[4] = {0, 0, 0, 0};         // ... and the first K dwords its lanes computed: they belong one lane down
-	__amdgpu_buffer_rsrc_t pdst = make_rsrc(dbase, 0);     // where the previous GROUP's last segment goes
+	uint32_t carry[4] = {0, 0, 0, 0};      // in lane 0: the last K dwords of lane 63 of the previous position of the row
+	uint32_t outp[DW] = {};                // the previous position's units: dwords KD.. of its lanes (the first DW - KD dwords of a unit)
+	uint32_t tp[KD > 0 ? KD : 1] = {};     // ... and the first KD dwords its lanes computed: they belong one lane down
+	__amdgpu_buffer_rsrc_t pdst = make_rsrc(dbase, 0);     // where the previous GROUP's last position goes
 	if constexpr (NARROW != 0)
 	{
 		// Rows of one or two positions (chroma of 1080p 4:2:0 at 10 bit, of 2160p at 8 bit: 2 KiB and less).  Walked row by
@@ -961,7 +619,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 				const int k = kg + u / P;                              // the slot's row
 				const bool valid = k < k1, nvalid = k + RPG < k1;      // wave-uniform
 				const __amdgpu_buffer_rsrc_t nsrc = make_rsrc(sbase + (nvalid ? row_off(k + RPG) : 0u), nvalid ? pd.rowbytes : 0u);
-				const __amdgpu_buffer_rsrc_t cdst = make_rsrc(dbase + (valid ? row_off(k) : 0u), valid ? pd.rowbytes : 0u);
+				const __amdgpu_buffer_rsrc_t cdst = make_rsrc(dbase + (valid ? row_offd(k) : 0u), valid ? (OUT8 ? pd.drowbytes : pd.rowbytes) : 0u);
 				uint32_t t[4];
 #pragma unroll
 				for (int d = 0; d < K; d++) t[d] = lane_up(p == 0 ? 0u : carry[d], w[u][4 - K + d]);
@@ -969,7 +627,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 				for (int d = 0; d < K; d++) carry[d] = rot_up(w[u][4 - K + d]);
 #pragma unroll
 				for (int d = K; d < 4; d++) asm volatile("v_mov_b32 %0, %1" : "=v"(t[d]) : "v"(w[u][d - K]));
-				load_seg<LDA>(nsrc, lane16 + p * (kMaxUnits * 16), 0, w[u]);
+				load_seg<LDA>(nsrc, lane16 + p * UB, 0, w[u]);
 				if (valid)
 				{
 					const int j = base + RSTR * k - Rabs * RPB;        // row inside the block row
@@ -1004,35 +662,37 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 						grain_unit<DEPTH, BW, false, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, 0, 0, edge_on, first, lo2, hi2);
 					}
 				}
+				uint32_t o[DW];
+				results(t, o);
 				// the previous position (of this row, or the last one of the row before: `pdst` is its row) is complete
 #pragma unroll
-				for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(rot_down(t[d]), tp[d]);
-				store_b128<STA>(pdst, lane16 + ((p + P - 1) % P) * (kMaxUnits * 16), 0, outp);
+				for (int d = 0; d < KD; d++) outp[DW - KD + d] = lane_down(rot_down(o[d]), tp[d]);
+				store_unit<DW, STA>(pdst, laned + ((p + P - 1) % P) * UBD, outp);
 				pdst = cdst;
 #pragma unroll
-				for (int d = K; d < 4; d++) outp[d - K] = t[d];
+				for (int d = KD; d < DW; d++) outp[d - KD] = o[d];
 #pragma unroll
-				for (int d = 0; d < K; d++) tp[d] = t[d];
+				for (int d = 0; d < KD; d++) tp[d] = o[d];
 #if VFGS_SCHED_FENCE
 				__builtin_amdgcn_sched_barrier(0);
 #endif
 			}
 		}
 #pragma unroll
-		for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(0u, tp[d]);
-		store_b128<STA>(pdst, lane16 + (P - 1) * (kMaxUnits * 16), 0, outp);
+		for (int d = 0; d < KD; d++) outp[DW - KD + d] = lane_down(0u, tp[d]);
+		store_unit<DW, STA>(pdst, laned + (P - 1) * UBD, outp);
 		return;
 	}
-	// one row; `overlap` is a type so that the walk of the (rare) overlap lines is code of its own: the hot loop carries
-	// neither their arithmetic nor a branch around it
-	auto walk_row = [&](auto overlap, const int k) {
+	// one row, groups [g_lo, g_hi) of it (a part); `overlap` is a type so that the walk of the (rare) overlap lines is code of
+	// its own: the hot loop carries neither their arithmetic nor a branch around it
+	auto walk_row = [&](auto overlap, const int k, const int g_lo, const int g_hi) {
 		constexpr bool OV = decltype(overlap)::value;
 		const int j = base + RSTR * k - Rabs * RPB;    // row inside the block row
 		const int jrow = j * SUBY;
 		const uint32_t rowoff = (uint32_t)j * RS, uprowoff = (uint32_t)(RPB + j) * RS;
 		const int wc_ = jrow == 0 ? (SUBY > 1 ? 20 : 12) : 24, wu_ = jrow == 0 ? (SUBY > 1 ? 20 : 24) : 12;
-		const uint32_t ro = row_off(k);
-		for (int g = 0; g < ngroups; g++)
+		const uint32_t ro = row_off(k), rod = row_offd(k);
+		for (int g = g_lo; g < g_hi; g++)
 		{
 			// the group after this one (this row's next, or the next row's first): what the four refills fetch
 			const bool lastg = g + 1 == ngroups;
@@ -1040,13 +700,13 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 			const bool nvalid = !lastg || k + 1 < k1;
 			const uint32_t nso = nvalid ? (lastg ? row_off(k + 1) : ro) + (uint32_t)ng * GB : 0u;
 			const __amdgpu_buffer_rsrc_t nsrc = make_rsrc(sbase + nso, nvalid ? left(ng) : 0u);
-			const __amdgpu_buffer_rsrc_t cdst = make_rsrc(dbase + (ro + (uint32_t)g * GB), left(g));
-			const uint8_t* pe = lds + idx0 + (uint32_t)(g * NU * BPS * 4);
+			const __amdgpu_buffer_rsrc_t cdst = make_rsrc(dbase + (rod + (uint32_t)g * GBD), leftd(g));
+			const uint8_t* pe = lds + idx0 + (uint32_t)((g - g_lo) * NU * BPS * 4);    // (the table holds the part that begins at group g_lo)
 			const int clg = cl + g * NU * SSTEP;
 #pragma unroll
 			for (int u = 0; u < NU; u++)
 			{
-				const bool firsts = u == 0 && g == 0;                    // first segment of the row
+				const bool firsts = u == 0 && g == 0;                    // first position of the row
 				// assemble my 16 bytes: the last K dwords of the unit of the lane before me, the first 4 - K of mine
 				uint32_t t[4];
 #pragma unroll
@@ -1057,8 +717,8 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 				// else and be copied back at the end of the loop -- behind a wait for all four refills)
 #pragma unroll
 				for (int d = K; d < 4; d++) asm volatile("v_mov_b32 %0, %1" : "=v"(t[d]) : "v"(w[u][d - K]));
-				// the registers are free: refill them with the segment four steps ahead
-				load_seg<LDA>(nsrc, lane16 + u * (kMaxUnits * 16), 0, w[u]);
+				// the registers are free: refill them with the position four steps ahead
+				load_seg<LDA>(nsrc, lane16 + u * UB, 0, w[u]);
 				if (NU * g + u < tsegs)
 				{
 					bool edge_on[NEF];
@@ -1079,17 +739,19 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 					for (int rr = 0; rr < NR; rr++) up.pa[rr] = OV ? *(const uint32_t*)(pe + PT_UP + (u * BPS + rr) * 4) + pairoff : 0u;
 					grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, OV ? wc_ : 0, OV ? wu_ : 0, edge_on, first, lo2, hi2);
 				}
-				// the previous segment's units are complete once the K dwords its lanes computed have moved one lane down; its
-				// lane 63 takes them from my lane 0 (the previous segment of a row's first one is the last of another row:
+				uint32_t o[DW];
+				results(t, o);
+				// the previous position's units are complete once the KD dwords its lanes computed have moved one lane down; its
+				// lane 63 takes them from my lane 0 (the previous position of a row's first one is the last of another row:
 				// its lane 63 lies behind that row's end and is never stored)
 #pragma unroll
-				for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(rot_down(t[d]), tp[d]);
-				if (u == 0) store_b128<STA>(pdst, lane16 + (NU - 1) * (kMaxUnits * 16), 0, outp);
-				else store_b128<STA>(cdst, lane16 + (u - 1) * (kMaxUnits * 16), 0, outp);
+				for (int d = 0; d < KD; d++) outp[DW - KD + d] = lane_down(rot_down(o[d]), tp[d]);
+				if (u == 0) store_unit<DW, STA>(pdst, laned + (NU - 1) * UBD, outp);
+				else store_unit<DW, STA>(cdst, laned + (u - 1) * UBD, outp);
 #pragma unroll
-				for (int d = K; d < 4; d++) outp[d - K] = t[d];
+				for (int d = KD; d < DW; d++) outp[d - KD] = o[d];
 #pragma unroll
-				for (int d = 0; d < K; d++) tp[d] = t[d];
+				for (int d = 0; d < KD; d++) tp[d] = o[d];
 #if VFGS_SCHED_FENCE
 				__builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1097,62 +759,48 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 			pdst = cdst;
 		}
 	};
-	for (int k = k0; k < k1; k++)
+	for (int h = 0;;)
 	{
-		const int jrow = (base + RSTR * k - Rabs * RPB) * SUBY;
-		if (Rabs > 0 && jrow <= 1) walk_row(std::true_type(), k);      // blends in the block above (vfgs_hw.c:173-188, 223-229)
-		else walk_row(std::false_type(), k);
+		// part h of my rows (all of them -- every group -- where the row's blocks fit one table: every BASELINE size)
+		const int g_lo = h * GPP, g_hi = (h + 1 == nparts) ? ngroups : (h + 1) * GPP;
+		for (int k = k0; k < k1; k++)
+		{
+			const int jrow = (base + RSTR * k - Rabs * RPB) * SUBY;
+			if (Rabs > 0 && jrow <= 1) walk_row(std::true_type(), k, g_lo, g_hi);      // blends in the block above (vfgs_hw.c:173-188, 223-229)
+			else walk_row(std::false_type(), k, g_lo, g_hi);
+		}
+		if (++h >= nparts) break;
+		// the table of the next part: every wave is done reading this one; the LFSR words come out of L2 while the ring's
+		// refills are in flight (wide pictures only: one row per wave, so the walk simply continues where it stopped)
+		__syncthreads();
+		u32x2 wcn[NPE], wun[NPE];
+		param_loads(h * kTileBlocks, wcn, wun);
+		param_table(h * kTileBlocks, wcn, wun);
+		__syncthreads();
 	}
-	// the last segment of my last row
+	// the last position of my last row
 #pragma unroll
-	for (int d = 0; d < K; d++) outp[4 - K + d] = lane_down(0u, tp[d]);
-	store_b128<STA>(pdst, lane16 + (NU - 1) * (kMaxUnits * 16), 0, outp);
+	for (int d = 0; d < KD; d++) outp[DW - KD + d] = lane_down(0u, tp[d]);
+	store_unit<DW, STA>(pdst, laned + (NU - 1) * UBD, outp);
 }
 
-// 8-bit planes with 8-sample blocks hold three block runs and two edges per lane (LaneMap): those kernels get the
-// registers of one workgroup less per CU instead of spilling in the row loop
-template <int DEPTH, int CSUBX>
-constexpr int wg_per_cu() { return (DEPTH == 8 && CSUBX == 2 && VFGS_WG_PER_CU > VFGS_WG_PER_CU_8BIT_SUB) ? VFGS_WG_PER_CU_8BIT_SUB : VFGS_WG_PER_CU; }
-
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool AL>
-__global__ __launch_bounds__(kWavesPerWG * 64, (kWavesPerWG * wg_per_cu<DEPTH, CSUBX>() + 3) / 4) void grain_kernel(const KernelArgs a)
-{
-	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
-	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes];
-
-	const int lane = threadIdx.x & 63;
-	// wave-uniform by construction; telling the compiler keeps the decoding, row offsets and buffer
-	// descriptors in SGPRs (otherwise every buffer instruction gets a waterfall loop)
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-	const int f = blockIdx.y;            // grid: x = workgroup inside the frame, y = frame of the batch
-	int r = blockIdx.x;
-	if (r < a.pd[0].wgs)
-		run_plane<DEPTH, 16, 1, 1, L.y_rs, OUT8, L.y_bytes, ONEY, AL, L.y_neg>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
-	else
-	{
-		r -= a.pd[0].wgs;
-		const int comp = 1 + (r >= a.pd[1].wgs);
-		if (comp == 2) r -= a.pd[1].wgs;
-		run_plane<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, OUT8, L.c_bytes, ONEC, AL, L.c_neg>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
-	}
-}
-
-// row-walk kernel (run_plane_rw): in place or out of place, same sample size; workgroups numbered frame -> plane -> block row -> part
-// Waves per SIMD the row-walk kernels are allocated for.  The 8-bit all-one-pattern kernels need 97..100 registers, one
+// Waves per SIMD the kernels are allocated for.  The 8-bit all-one-pattern kernels need 97..100 registers, one
 // allocation granule above the 96 of five waves: asking for five costs one register spilled in the prologue and reloaded
 // once per row (not in the group loop) and is worth 3 % (profiles/r03_ab22_lds_probes_and_occupancy.log); the general-form
 // kernels are held at four by their LDS image, the others by spills.
 template <int DEPTH, bool ONEY, bool ONEC>
 constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && VFGS_WG_PER_CU == 4) ? 5 : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
 
-template <int DEPTH, int CSUBX, int CSUBY, bool ONEY, bool ONEC>
+// in place or out of place; workgroups numbered frame -> plane -> block row -> part of the block row
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE>
 __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC>())) void grain_rw_kernel(const KernelArgs a)
 {
 	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes + kParamBytes];
 
 	const int lane = threadIdx.x & 63;
+	// wave-uniform by construction; telling the compiler keeps the decoding, row offsets and buffer descriptors in SGPRs
+	// (otherwise every buffer instruction gets a waterfall loop)
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	// grid: x = (workgroup inside the frame, frame of a group of 2^lfronts frames), y = group of frames.  Large frames are swept
 	// two at a time: the workgroups of frames 2m and 2m + 1 are dealt out alternately (measured: +1.6 % at 4320p, nothing at 2160p;
@@ -1161,119 +809,67 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 	int r = (int)(blockIdx.x >> a.lfronts);
 	if (f >= a.nframes) return;
 	if (r < a.pd[0].wgs)
-		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0, OUT8, WIDE>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
 		const int comp = 1 + (r >= a.pd[1].wgs);
 		if (comp == 2) r -= a.pd[1].wgs;
 		// horizontally subsampled chroma rows of one or two positions (2 KiB and less: 1080p at 10 bit, 2160p at 8 bit): several rows per group
-		if (CSUBX == 2 && a.pd[1].rw_segs == 2)
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 2>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
-		else if (CSUBX == 2 && a.pd[1].rw_segs == 1)
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 1>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+		if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 2)
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 2, OUT8, WIDE>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+		else if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 1)
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 1, OUT8, WIDE>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 		else
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 0>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 0, OUT8, WIDE>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 	}
 }
 
 // ---------------------------------------------------------------------------------------
 // host-side launcher (called from vfgs_host.cpp)
 
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool AL>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE>
 static hipError_t launch_t(const KernelArgs& a, int grid, hipStream_t stream)
 {
-	hipLaunchKernelGGL((grain_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC, AL>), dim3(grid, a.nframes), dim3(kWavesPerWG * 64), 0, stream, a);
+	hipLaunchKernelGGL((grain_rw_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC, WIDE>), dim3((unsigned)grid << a.lfronts, ((unsigned)a.nframes + (1u << a.lfronts) - 1) >> a.lfronts),
+	                   dim3(kWavesPerWG * 64), 0, stream, a);
 	return hipGetLastError();
 }
 
-// every plane type's rows are whole 16-byte units except 8-bit planes with 8-sample blocks and an odd number of blocks:
-// only those formats carry the kernels with shifted accesses next to the aligned ones
-template <int DEPTH, int CSUBX>
-constexpr bool has_shifted() { return !VFGS_ALIGNED || (DEPTH == 8 && CSUBX == 2); }
-
-template <int DEPTH, int CSUBX, int CSUBY, bool ONEY, bool ONEC>
-static hipError_t launch_al(const KernelArgs& a, int mode, int grid, hipStream_t stream)
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
+static hipError_t launch_form(const KernelArgs& a, bool oney, bool onec, bool wide, int grid, hipStream_t stream)
 {
-	const bool aligned = mode != 0;
-	if constexpr (VFGS_ALIGNED != 0)
-	{
-		if (mode == 2)
-		{
-			hipLaunchKernelGGL((grain_rw_kernel<DEPTH, CSUBX, CSUBY, ONEY, ONEC>), dim3((unsigned)grid << a.lfronts, ((unsigned)a.nframes + (1u << a.lfronts) - 1) >> a.lfronts),
-			                   dim3(kWavesPerWG * 64), 0, stream, a);
-			return hipGetLastError();
-		}
-		if (aligned) return launch_t<DEPTH, CSUBX, CSUBY, false, ONEY, ONEC, true>(a, grid, stream);
+	if (wide) return (oney || onec) ? hipErrorInvalidValue : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, true>(a, grid, stream);
+	if (oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, true, false>(a, grid, stream);
+	if (oney) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, false, false>(a, grid, stream);
+	if (onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, false>(a, grid, stream);
+	return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, false>(a, grid, stream);
+}
+
+// out8: the destination holds 8-bit samples of a 10-bit path; oney / onec: the image holds the one-pattern form for luma /
+// chroma (vfgs_layout.h); wide: rows of more than kTileBlocks blocks (general form only); grid: workgroups per frame
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, int grid, hipStream_t stream)
+{
+	if ((out8 && depth != 10) || wide != (a.nblk > kTileBlocks)) return hipErrorInvalidValue;
+#define VFGS_CASE(D, X, Y)                                                                                         \
+	if (depth == D && csubx == X && csuby == Y)                                                                    \
+	{                                                                                                              \
+		if constexpr (D == 10) { if (out8) return launch_form<D, X, Y, true>(a, oney, onec, wide, grid, stream); } \
+		return launch_form<D, X, Y, false>(a, oney, onec, wide, grid, stream);                                     \
 	}
-	if constexpr (has_shifted<DEPTH, CSUBX>())
-		return launch_t<DEPTH, CSUBX, CSUBY, false, ONEY, ONEC, false>(a, grid, stream);
-	return hipErrorInvalidValue;
-}
-
-template <int DEPTH, int CSUBX, int CSUBY>
-static hipError_t launch_one(const KernelArgs& a, bool out8, bool oney, bool onec, int aligned, int grid, hipStream_t stream)
-{
-	if (DEPTH == 10 && out8) return launch_t<10, CSUBX, CSUBY, true, false, false, false>(a, grid, stream);    // fused 8-bit output: general form, shifted accesses
-	if (oney && onec) return launch_al<DEPTH, CSUBX, CSUBY, true, true>(a, aligned, grid, stream);
-	if (oney) return launch_al<DEPTH, CSUBX, CSUBY, true, false>(a, aligned, grid, stream);
-	if (onec) return launch_al<DEPTH, CSUBX, CSUBY, false, true>(a, aligned, grid, stream);
-	return launch_al<DEPTH, CSUBX, CSUBY, false, false>(a, aligned, grid, stream);
-}
-
-// oney / onec: the image holds the one-pattern form for luma / chroma (vfgs_layout.h); never with out8.
-// aligned: 0 = the plane descriptors were laid out for the kernels with shifted accesses, 1 = for the aligned tiled kernels
-// (aligned_ok()), 2 = for the row walk (rowwalk_ok()).
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int aligned, int grid, hipStream_t stream)
-{
-	if (out8 && (depth != 10 || oney || onec || aligned)) return hipErrorInvalidValue;
-#define VFGS_CASE(D, X, Y) if (depth == D && csubx == X && csuby == Y) return launch_one<D, X, Y>(a, out8, oney, onec, aligned, grid, stream)
-	VFGS_CASE(10, 2, 2); VFGS_CASE(10, 2, 1); VFGS_CASE(10, 1, 1); VFGS_CASE(10, 1, 2);
-	VFGS_CASE(8, 2, 2);  VFGS_CASE(8, 2, 1);  VFGS_CASE(8, 1, 1);  VFGS_CASE(8, 1, 2);
+	VFGS_CASE(10, 2, 2) VFGS_CASE(10, 2, 1) VFGS_CASE(10, 1, 1) VFGS_CASE(10, 1, 2)
+	VFGS_CASE(8, 2, 2) VFGS_CASE(8, 2, 1) VFGS_CASE(8, 1, 1) VFGS_CASE(8, 1, 2)
 #undef VFGS_CASE
 	return hipErrorInvalidValue;
 }
 
 // the name of the instantiation launch_grain() dispatches for these arguments, as the profiler prints it (vfgs_hip_last_launch_info)
-void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, int aligned)
+void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide)
 {
 	auto b = [](bool v) { return v ? "true" : "false"; };
-	if (depth == 10 && out8) snprintf(out, n, "grain_kernel<10,%d,%d,true,false,false,false>", csubx, csuby);
-	else if (VFGS_ALIGNED && aligned == 2) snprintf(out, n, "grain_rw_kernel<%d,%d,%d,%s,%s>", depth, csubx, csuby, b(oney), b(onec));
-	else snprintf(out, n, "grain_kernel<%d,%d,%d,false,%s,%s,%s>", depth, csubx, csuby, b(oney), b(onec), b(VFGS_ALIGNED && aligned == 1));
-}
-
-// may a launch use the aligned kernels?  (rows of both plane types are whole 16-byte units; not the narrowed destination)
-bool aligned_ok(int depth, int csubx, int nblk, bool out8)
-{
-	if (!VFGS_ALIGNED || out8) return false;
-	return !(depth == 8 && csubx == 2 && (nblk & 1));
-}
-
-// ... the row walk?  (additionally: a row's blocks fit the workgroup's parameter table)
-bool rowwalk_ok(int depth, int csubx, int nblk, bool out8)
-{
-#ifdef VFGS_NO_ROWWALK
-	return false;
-#endif
-	// (also 8-bit 4:2:x rows of an odd number of blocks, which end in HALF a unit: a row's descriptor holds exactly the row's
-	// bytes and the raw-buffer range check works per dword, so the last lane's access is cut in the middle -- loads return
-	// 0 for, stores drop, the dwords behind the row.  Measured: bit-exact incl. the stride padding, 0.50 instead of the
-	// tiled kernels' 0.35 at 3856x2160, profiles/r03_ab44_odd_block_counts.log)
-	(void)depth; (void)csubx;
-	return VFGS_ALIGNED && !out8 && nblk <= kTileBlocks;
+	snprintf(out, n, "grain_rw_kernel<%d,%d,%d,%s,%s,%s,%s>", depth, csubx, csuby, b(out8), b(oney), b(onec), b(wide));
 }
 
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec) { return image_layout(csubx, csuby, oney, onec); }
-
-// the plane type's lane layout, for the host's geometry: samples per lane, samples the unit grid is shifted, lanes per row
-void lane_layout(int depth, int bw, int nblk, int* shift_samples, int* lanes)
-{
-	const int ns = depth == 8 ? 16 : 8;
-	const bool pair = (ns == 8 && bw == 16);
-	const int shift = pair ? 8 : bw / 2;
-	*shift_samples = shift;
-	*lanes = (nblk * bw + shift + ns - 1) / ns;
-}
 
 }  // namespace vfgs

@@ -6,77 +6,48 @@
 namespace vfgs {
 
 constexpr int kSlots = 8;        // pattern slots per component, vfgs_hw.h:49
-constexpr int kMaxUnits = 64;    // 16-byte units per segment (one per lane)
-constexpr int kSegsPerTile = 4;  // segments a wave moves per row
+constexpr int kMaxUnits = 64;    // 16-byte units per position (one per lane)
 constexpr int kBlock = 16;       // luma samples per grain block
 
 // Tuning knobs (defaults are the shipped configuration; tools/dev/build_variant.sh overrides them).  They change HOW the
 // kernels run, never WHAT they compute: the timing-only probes with wrong output that rounds 2 and 3 kept in the kernel source
-// (their results: profiles/r02_variants*.log, r03_ab*.log) were removed in round 4.
+// (their results: profiles/r02_variants*.log, r03_ab*.log) were removed in round 4, and so were the knobs of
+// round 2's tiled kernels when the row walk became the only kernel family.
 #ifndef VFGS_WAVES
 #define VFGS_WAVES 4          // waves per workgroup (power of two); they share one LDS image
 #endif
-#ifndef VFGS_ROWS_PER_WAVE
-#define VFGS_ROWS_PER_WAVE 4  // rows of one tile a wave walks (block parameters are computed once for them): 1, 2, 4, 8
-#endif
 #ifndef VFGS_WG_PER_CU
-#define VFGS_WG_PER_CU 4  // resident workgroups per CU the register allocation is sized for
-#endif
-#ifndef VFGS_WG_PER_CU_8BIT_SUB
-#define VFGS_WG_PER_CU_8BIT_SUB 3   // ... for the 8-bit kernels with horizontally subsampled chroma (three block runs per lane)
-#endif
-#ifndef VFGS_LDAUX
-#define VFGS_LDAUX 0      // cache policy bits of the sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
-#endif
-#ifndef VFGS_STAUX
-#define VFGS_STAUX 0      // cache policy bits of the sample stores
-#endif
-#ifndef VFGS_PREFETCH
-#define VFGS_PREFETCH 1   // 1: a segment's registers are refilled with the next row right after its store
+#define VFGS_WG_PER_CU 4      // resident workgroups per CU the register allocation is sized for
 #endif
 #ifndef VFGS_SCHED_FENCE
-#define VFGS_SCHED_FENCE 1 // 1: a scheduling fence after every segment keeps its store and refill in program order
-#endif
-#ifndef VFGS_SPLIT_INTERLEAVE
-#define VFGS_SPLIT_INTERLEAVE 0   // 1: the workgroups that share a block row take every splits-th row instead of consecutive rows
-#endif
-#ifndef VFGS_ALIGNED
-#define VFGS_ALIGNED 1        // 1: whole aligned 16-byte units are moved (1 KiB line-aligned wave accesses) and rotated by one lane in
-                              //    registers; 0: every lane loads and stores the shifted 16 bytes it computes (round 2's first form)
-#endif
-#ifndef VFGS_LANE_SHIFT_DPP
-#define VFGS_LANE_SHIFT_DPP 1  // aligned kernels: 1 = rotate by one lane with DPP wave_shr / wave_shl, 0 = with ds_bpermute_b32
+#define VFGS_SCHED_FENCE 1    // 1: a scheduling fence after every position keeps its store and refill in program order
 #endif
 #ifndef VFGS_LDAUX_ALIGNED
-#define VFGS_LDAUX_ALIGNED 2  // cache policies of the aligned kernels: nontemporal
+#define VFGS_LDAUX_ALIGNED 2  // cache policy bits of the sample loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1): nontemporal
 #endif
 #ifndef VFGS_STAUX_ALIGNED
-#define VFGS_STAUX_ALIGNED 2
+#define VFGS_STAUX_ALIGNED 2  // ... of the sample stores
 #endif
-
 #ifndef VFGS_RW_CONSEC
-#define VFGS_RW_CONSEC 0      // row walk: 1 = a wave's rows are consecutive, 0 = the waves of a workgroup take every kWavesPerWG-th row
+#define VFGS_RW_CONSEC 0      // 1 = a wave's rows are consecutive, 0 = the waves of a workgroup take every kWavesPerWG-th row
 #endif
 
 // The product is built with every knob at its default (versatilefilmgrain_amd/build.py passes none).  The developer tools that
 // time variants (tools/dev/build_variant.sh, tools/gpu_variants.sh) define VFGS_DEV_BUILD; without it any
-// other value is a build error, so a stray -D cannot produce a library that silently computes something else -- and a
+// other value is a build error, so a stray -D cannot produce a library that silently runs something else -- and a
 // developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
 #if !defined(VFGS_DEV_BUILD)
-#if VFGS_WAVES != 4 || VFGS_ROWS_PER_WAVE != 4 || VFGS_WG_PER_CU != 4 || VFGS_WG_PER_CU_8BIT_SUB != 3 || VFGS_LDAUX != 0 || VFGS_STAUX != 0 || \
-    VFGS_PREFETCH != 1 || VFGS_SCHED_FENCE != 1 || VFGS_SPLIT_INTERLEAVE != 0 || VFGS_ALIGNED != 1 || VFGS_LANE_SHIFT_DPP != 1 || \
-    VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || defined(VFGS_NO_ROWWALK) || defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || \
-    defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_ALIGN_TEST) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_MIN_FILL_PCT) || defined(VFGS_RW_MIN_FILL_PCT)
-#error "libvfgs_hip: a tuning / ablation knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
+#if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
+    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT)
+#error "libvfgs_hip: a tuning knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
 #endif
 
 constexpr int kWavesPerWG = VFGS_WAVES;
-constexpr int kRowsPerWave = VFGS_ROWS_PER_WAVE;
 
-// Row-walk kernels (vfgs_kernel.hip "Row walk"): a wave streams whole rows, the workgroup's block parameters live in LDS
-// behind the table image: two tables (this block row's registers, the block row above's) of one dword per grain block of the
-// row + one block in front.  A row of at most kTileBlocks blocks is one tile; wider pictures keep the tiled kernels.
+// The kernels (vfgs_kernel.hip "Row walk"): a wave streams whole rows, the workgroup's block parameters live in LDS
+// behind the table image: two tables (this block row's registers, the block row above's) of one dword per grain block +
+// one block in front.  A table holds kTileBlocks blocks: a row of more blocks is walked in parts, the table refilled between them.
 constexpr int kTileBlocks = 512;
 constexpr int kParamEntries = kTileBlocks + 4;   // entry e = block e - 1; the lanes behind a row's end read up to block nblk + 2 (clamped values)
 constexpr int kParamTableBytes = (kParamEntries * 4 + 15) & ~15;
@@ -151,27 +122,19 @@ constexpr ImageLayout image_layout(int csubx, int csuby, bool one_y, bool one_c)
 
 // Geometry of one plane type (0 = luma, 1 = the two chroma planes) for one launch.
 //
-// A row of the plane is cut into 16-byte "units" (one per lane and access), `upt` consecutive units
-// form a segment (one wave access, <= 1 KiB), kSegsPerTile consecutive segments a tile; the unit grid
-// is shifted left against the block grid so that block edges lie inside units / lane pairs
-// (vfgs_kernel.hip "Lanes").  One workgroup of kWavesPerWG waves covers `tiles_w` tiles x
-// (ppb row phases x bpw block rows); wave i: tile i % tiles_w, phase (i / tiles_w) % ppb, block row
-// (i / tiles_w) / ppb; it walks rows phase, phase + ppb, ... of ONE block row (or of the `splits`-th
-// part of it), so the block parameters of its lanes are computed once.
+// A row of the plane is cut into 16-byte "units" (one per lane and access), 64 consecutive units are a "position" (one wave
+// access, 1 KiB); the lanes compute bytes shifted left against the units so that block edges lie inside lanes / lane pairs
+// (vfgs_kernel.hip "Lanes"), which is why a row has one position more than its units fill.  One workgroup = kWavesPerWG waves
+// x rw_rpw rows each (wave w: rows w, w + kWavesPerWG, ... of the workgroup's part of ONE block row), rw_splits workgroups per
+// block row.
 struct PlaneDesc {
 	uint32_t pitch, dpitch;       // row pitch of source / destination, bytes
-	uint32_t extent, dextent;     // bytes of one frame's stripe of this plane: buffer range check
 	uint64_t fpitch, dfpitch;     // bytes from frame f to frame f+1
 	uint32_t rowbytes, drowbytes; // bytes of a row the reference touches (whole blocks)
 	int nrows;                    // rows of the stripe
-	int upt, segs, tiles;         // units per segment (<= 64), segments and tiles per row
-	int tiles_w, ppb, bpw, splits;   // powers of two
-	int ltiles_w, lppb, lsplits;     // their logarithms
-	int colgroups;                // workgroups along a row = ceil(tiles / tiles_w)
 	int wgs;                      // workgroups per frame for ONE plane of this type
-	// row walk: a workgroup = kWavesPerWG waves x rw_rpw rows each (wave w: rows w, w + kWavesPerWG, ... of the workgroup's
-	// part of ONE block row), rw_splits workgroups per block row; a row = rw_segs wave accesses of 64 units
-	int rw_segs, rw_rpw, rw_splits, rw_lsplits;
+	int rw_segs;                  // positions per row
+	int rw_rpw, rw_splits, rw_lsplits;
 };
 
 // One launch = nframes x (luma workgroups + 2 x chroma workgroups); workgroups are numbered in memory
@@ -191,7 +154,7 @@ struct KernelArgs {
 	int nblk;                 // 16-sample blocks per line = ceil(width/16), vfgs_hw.c:301
 	int nbrows;               // block rows the stripe touches
 	int nframes;
-	int lfronts;              // row walk: log2 of the frames of a batch that are swept at the same time (their workgroups are dealt out in turn)
+	int lfronts;              // log2 of the frames of a batch that are swept at the same time (their workgroups are dealt out in turn)
 	uint32_t lo2[2], hi2[2];  // clip bounds in sample units (I_min<<bs ...) in both halves of a dword, per plane type (vfgs_hw.c:264-267)
 };
 
