@@ -63,8 +63,10 @@ void vfgs_add_grain_line(void* Y, void* U, void* V, int y, int width);
 
 /* vfgs_add_grain_line and lines the caller has not handed over yet.  One drop-in call is one line in host memory and
  * must be complete on return (~90 us: copy in, launch, copy out).  The library therefore works ahead: on a miss it
- * computes the lines FOLLOWING the requested one as well (up to 256), keeps those results, and serves the next calls
- * from them when they are exactly the predicted lines with unchanged input bytes.  Lines not yet handed over are only
+ * starts computing the lines FOLLOWING the requested one as well -- the rest of the frame, in stripes of about 2 MB whose
+ * upload, kernel and download are pipelined on three streams while the caller walks through the stripes already back --
+ * keeps those results, and serves the next calls from them when they are exactly the predicted lines with unchanged
+ * input bytes.  Lines not yet handed over are only
  * ever READ, and only inside rows the caller has proven to own: either this same buffer (same line-0 pointers and
  * width) has been walked top to bottom once before, or the caller has said so with vfgs_hip_declare_frame().  A first
  * frame, or a frame in a buffer the previous walk did not go through, is computed line by line.
@@ -128,8 +130,10 @@ int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned wi
 /* Out-of-place form of the call above: reads sY/sU/sV, writes dY/dU/dV (same geometry and
  * pitches; src == dst is allowed and is what the in-place entry points pass).  This is how a
  * decoder uses film grain -- the clean picture stays a reference frame, the grained copy goes
- * to the display queue -- and it is the faster form: on MI355X an in-place read-modify-write
- * stream tops out at ~5.5 TB/s, a src->dst stream at ~6.3 TB/s (tools/copy_ceiling.hip). */
+ * to the display queue.  Same kernels, same speed within 2-3 % (profiles/r04_config_matrix*.jsonl:
+ * 4320p 0.733 out of place / 0.716 in place of the 8 TB/s peak; as PURE streams the order is the
+ * other way round on MI355X -- in-place nontemporal 6.6 TB/s, src->dst copy 5.0-5.3 TB/s,
+ * BENCH_r03 / bench.py copy_ceilings_gbs). */
 int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV,
                                 unsigned width, unsigned frame_height, unsigned part_y, unsigned part_height,
                                 unsigned stride, unsigned cstride, unsigned nframes,

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 (gloo): the multi-GPU decomposition and its torch.distributed plumbing.
+"""CPU, world_size 2 and 8 (gloo): the multi-GPU decomposition and its torch.distributed plumbing.
 
 The product kernels need a GPU; what can be checked here is what the N > 1 path rests on:
  * bench.split_rows partitions the block rows exactly (contiguous, sizes differ by <= 1);
@@ -81,16 +81,18 @@ def _rank(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_ranks_stripes_assemble_to_whole_frame():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_stripes_assemble_to_whole_frame(world):
+    """world 8 = the node the scaling bench runs on (13 block rows -> stripes of 2,2,2,2,2,1,1,1 rows)."""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, ret)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + world) % 2000
+    procs = [ctx.Process(target=_rank, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, tmax = ret.get(timeout=300)
+    ok, tmax = ret.get(timeout=600)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert ok
-    assert tmax == 2.0
+    assert tmax == float(world)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Developer tool: the reference's own command line program, unchanged (vfgs_main.c + vfgs_fw.c + yuv.c), linked against
+libvfgs_hip.so (oracle/_ref/vfgs_hip_cli) next to the all-reference binary (oracle/_ref/vfgs_ref): seconds per frame INCLUDING
+the program's file I/O (stdio on /dev/shm), from the difference of two runs with different frame counts (process start, GPU
+initialisation and the first, line-by-line walk of the buffer cancel out).  Outputs must be byte-identical."""
+import hashlib
+import json
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+import vfgs_testlib as T  # noqa: E402
+
+
+def run(exe, w, h, n, inp, out):
+    t0 = time.perf_counter()
+    subprocess.run([str(exe), "-w", str(w), "-h", str(h), "-b", "10", "-n", str(n), "-r", "12345", str(inp), str(out)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    return time.perf_counter() - t0
+
+
+def main():
+    cli, ref = T.REF_DIR / "vfgs_hip_cli", T.REF_DIR / "vfgs_ref"
+    assert cli.exists() and ref.exists(), "oracle/_ref binaries were not prebuilt (make -C oracle ref where /root/reference exists)"
+    shm = Path("/dev/shm")
+    for (w, h, n1, n2) in ((1920, 1080, 10, 40), (3840, 2160, 6, 18), (7680, 4320, 3, 9)):
+        frames, _ = T.lcg_frames(w, h, 10, 2, 2, 3)
+        inp = shm / f"vfgs_cli_in_{w}.yuv"
+        with open(inp, "wb") as f:
+            for i in range(n2):
+                f.write(frames[i % 3].picture_bytes())
+        res = {"size": f"{w}x{h}", "depth": 10, "cfg": "built-in default SEI (vfgs_main.c:69-110)", "frames": [n1, n2]}
+        md5 = {}
+        for name, exe in (("reference", ref), ("hip", cli)):
+            out = shm / f"vfgs_cli_out_{name}.yuv"
+            run(exe, w, h, n1, inp, out)            # (also warms the page cache)
+            t1 = min(run(exe, w, h, n1, inp, out) for _ in range(2))
+            t2 = min(run(exe, w, h, n2, inp, out) for _ in range(2))
+            md5[name] = hashlib.md5(out.read_bytes()).hexdigest()
+            per = (t2 - t1) / (n2 - n1)
+            res[f"{name}_ms_per_frame_incl_file_io"] = round(per * 1e3, 2)
+            res[f"{name}_frames_per_s"] = round(1 / per, 1)
+            res[f"{name}_process_s_for_{n1}_frames"] = round(t1, 2)
+            out.unlink()
+        inp.unlink()
+        res["identical_output"] = md5["reference"] == md5["hip"]
+        res["speedup"] = round(res["reference_ms_per_frame_incl_file_io"] / res["hip_ms_per_frame_incl_file_io"], 1)
+        print(json.dumps(res), flush=True)
+        if not res["identical_output"]:
+            sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -21,11 +21,12 @@ def main():
     h = hw.VfgsHip(device=0)
     T.replay(h, T.load_trace("fgs_sei_10_420"))
     st = torch.cuda.current_stream().cuda_stream
-    for ranks in (1, 2, 4, 8):
+    import itertools
+    for scaling, ranks in itertools.product(("weak", "strong"), (1, 2, 4, 8)):
         nbr = (H + 15) // 16
         rows = nbr // ranks + (1 if nbr % ranks else 0)
         part_h = min(rows * 16, H)
-        frames = 8 * ranks
+        frames = 8 * ranks if scaling == "weak" else 8        # bench.py: weak = ranks x batch frames per step, strong = batch frames
         Y = torch.zeros((part_h, W), dtype=torch.int16, device="cuda")
         U = torch.zeros((part_h // 2, W // 2), dtype=torch.int16, device="cuda")
         V = torch.zeros((part_h // 2, W // 2), dtype=torch.int16, device="cuda")
@@ -47,8 +48,9 @@ def main():
             host.append(1e6 * (t1 - t0) / calls)
             total.append(1e6 * (t2 - t0) / calls)
         host.sort(); total.sort()
-        print(f"ranks {ranks}: {frames} frames x {part_h} lines per call: host {host[len(host)//2]:7.1f} us per call, "
-              f"host+GPU {total[len(total)//2]:7.1f} us per call")
+        hm, tm = host[len(host) // 2], total[len(total) // 2]
+        print(f"{scaling:6s} ranks {ranks}: {frames:2d} frames x {part_h:4d} lines per call: host {hm:7.1f} us per call, "
+              f"host+GPU {tm:7.1f} us per call (host = {100 * hm / tm:4.1f} % of it; it runs ahead of the GPU while that stays < 100 %)")
 
 
 if __name__ == "__main__":

@@ -163,18 +163,21 @@ void sei_luts(const fgs_sei* cfg, const PatternList& pl, int c, unsigned char sl
 
 // ---- AFGS1 -----------------------------------------------------------------------------
 
-// scaling function: linear between the given points, zero outside (vfgs_fw.c:649-661)
-void piecewise_linear(unsigned char lut[256], const unsigned char* in, const unsigned char* out, int n)
+// AFGS1 scaling function -> scale LUT: zero outside the points, between two points the rounded interpolation of
+// vfgs_fw.c:649-661 (integer division that truncates towards zero, also for falling segments).  Segments are half-open
+// [x[s], x[s+1]): the reference writes every segment including its end point and the next segment then rewrites that
+// entry with its own start value -- the same bytes; only the last segment keeps its end point.
+void scaling_lut(unsigned char lut[256], const unsigned char* x, const unsigned char* y, int npoints)
 {
 	memset(lut, 0, 256);
-	for (int k = 1; k < n; k++)
+	for (int s = 0; s + 1 < npoints; s++)
 	{
-		const int din = in[k] - in[k - 1];
-		const int dout = (int)out[k] - out[k - 1];
-		if (din <= 0)
+		const int x0 = x[s], span = x[s + 1] - x0, rise = (int)y[s + 1] - (int)y[s];
+		if (span <= 0)
 			fw_die("AFGS1 scaling points must be in increasing order (vfgs_fw.c:656)");
-		for (int i = 0; i <= din; i++)
-			lut[in[k - 1] + i] = (unsigned char)(out[k - 1] + (dout * i + din / 2) / din);
+		const int stop = x0 + span + (s + 2 == npoints ? 1 : 0);
+		for (int t = x0; t < stop; t++)
+			lut[t] = (unsigned char)(y[s] + (rise * (t - x0) + span / 2) / span);
 	}
 }
 
@@ -229,13 +232,13 @@ void vfgs_init_afgs1(fgs_afgs1* cfg)
 
 	vfgs_set_seed(cfg->grain_seed | ((uint32_t)cfg->grain_seed << 16));   // vfgs_fw.c:672
 
-	piecewise_linear(lut, cfg->point_y_values, cfg->point_y_scaling, cfg->num_y_points);
+	scaling_lut(lut, cfg->point_y_values, cfg->point_y_scaling, cfg->num_y_points);
 	vfgs_set_scale_lut(0, lut);
 	if (!cfg->chroma_scaling_from_luma)
-		piecewise_linear(lut, cfg->point_cb_values, cfg->point_cb_scaling, cfg->num_cb_points);
+		scaling_lut(lut, cfg->point_cb_values, cfg->point_cb_scaling, cfg->num_cb_points);
 	vfgs_set_scale_lut(1, lut);
 	if (!cfg->chroma_scaling_from_luma)
-		piecewise_linear(lut, cfg->point_cr_values, cfg->point_cr_scaling, cfg->num_cr_points);
+		scaling_lut(lut, cfg->point_cr_values, cfg->point_cr_scaling, cfg->num_cr_points);
 	vfgs_set_scale_lut(2, lut);
 
 	if (lag < 1 || lag > 3)

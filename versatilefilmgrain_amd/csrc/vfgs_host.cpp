@@ -514,15 +514,54 @@ struct State {
 		unsigned frame_h = 0;                 // lines of the buffer the caller has proven to own (see line_call), 0 = unknown
 		const uint8_t *bY = nullptr, *bU = nullptr, *bV = nullptr;   // plane pointers of line 0 of the walk in progress
 		bool declared = false;                // frame_h and the pitches come from vfgs_hip_declare_frame
-		// one pre-computed stripe
+		// the stripes computed ahead of the caller's walk: a ring of slots, each with pinned snapshots of the caller's lines
+		// (`in`, also the upload source), pinned results (`out`) and a device stripe; upload, kernel and download of a stripe
+		// run on three streams, so the stripes further down the frame travel while the caller consumes this one
+		static constexpr int kRing = 3;
+		struct Slot {
+			bool used = false, waited = false;
+			unsigned y0 = 0, n = 0, crow0 = 0;
+			uint8_t* in[3] = {nullptr, nullptr, nullptr};
+			uint8_t* out[3] = {nullptr, nullptr, nullptr};
+			size_t cap[3] = {0, 0, 0};
+			void* dev[3] = {nullptr, nullptr, nullptr};
+			size_t dcap[3] = {0, 0, 0};
+			hipEvent_t up_done = nullptr, run_done = nullptr, done = nullptr;
+		} slot[kRing];
+		hipStream_t up = nullptr, run = nullptr, down = nullptr;
 		bool valid = false;
 		uint64_t gen = 0;
-		unsigned y0 = 0, n = 0, next = 0, width = 0, crow0 = 0;
+		int head = 0;                         // slot of the stripe that holds line `next`
+		unsigned next = 0, width = 0;         // the line the next call is expected to bring
+		unsigned base_y = 0;                  // Y0/U0/V0 address this line
+		unsigned issued_end = 0, frame_end = 0, stripe_lines = 0;   // first line not yet computed ahead; end of the proven rows
 		const uint8_t *Y0 = nullptr, *U0 = nullptr, *V0 = nullptr;
-		uint8_t* in[3] = {nullptr, nullptr, nullptr};    // pinned: what was read from the caller's lines
-		uint8_t* out[3] = {nullptr, nullptr, nullptr};   // pinned: their results
-		size_t cap[3] = {0, 0, 0};
 		unsigned rowlen[3] = {0, 0, 0}, dpitch[3] = {0, 0, 0};
+		uint64_t spec[4] = {0, 0, 0, 0};      // the seed registers behind the last stripe computed ahead {rnd, rnd_up, line_rnd, line_rnd_up}
+		uint64_t stripes_issued = 0, stripes_dropped = 0;
+		void release()
+		{
+			for (Slot& sl : slot)
+			{
+				for (int i = 0; i < 3; i++)
+				{
+					if (sl.in[i]) (void)hipHostFree(sl.in[i]);
+					if (sl.out[i]) (void)hipHostFree(sl.out[i]);
+					if (sl.dev[i]) (void)hipFree(sl.dev[i]);
+					sl.in[i] = sl.out[i] = nullptr; sl.dev[i] = nullptr; sl.cap[i] = sl.dcap[i] = 0;
+				}
+				if (sl.up_done) (void)hipEventDestroy(sl.up_done);
+				if (sl.run_done) (void)hipEventDestroy(sl.run_done);
+				if (sl.done) (void)hipEventDestroy(sl.done);
+				sl.up_done = sl.run_done = sl.done = nullptr;
+				sl.used = sl.waited = false;
+			}
+			if (up) (void)hipStreamDestroy(up);
+			if (run) (void)hipStreamDestroy(run);
+			if (down) (void)hipStreamDestroy(down);
+			up = run = down = nullptr;
+			valid = false;
+		}
 	} la;
 
 	State()
@@ -1217,76 +1256,201 @@ int run_host_frames(void* const* Y, void* const* U, void* const* V, unsigned nfr
 // The drop-in call hands over ONE line and must be complete on return, which costs a full
 // H2D + launch + D2H + sync (~90 us) per line.  The reference's frame loop (vfgs_main.c:664-682)
 // however walks a frame that is already complete in host memory, top to bottom, with fixed
-// row pitches.  So once the pitches are known from two consecutive calls, a miss computes the
-// stripe [y, y+n) in one round trip from the lines the caller has NOT handed over yet, keeps
-// their inputs and results in pinned buffers, and writes back only line y.  A later call that
-// is exactly the predicted next line (same y, pointers, width, no state change in between) and
-// whose input bytes still equal what was read ahead is served by a memcpy; anything else drops
-// the stripe and recomputes.  Lines the caller has not handed over are never written, the seed
-// registers advance per call exactly as before, so the observable behaviour is unchanged.
+// row pitches.  So once the pitches are known from two consecutive calls, a miss at line y starts
+// computing the REST of the frame from the lines the caller has not handed over yet, in stripes of
+// ~2 MB that travel through a ring of three slots: snapshot of the caller's lines into pinned
+// memory, upload, kernel, download into pinned memory, on three streams.  The call returns as soon
+// as the first stripe is back; while the caller walks through a stripe the next two are in flight,
+// and entering a stripe queues the one after those (round 3 did one synchronous round trip per 256
+// lines: 17 per 4320p frame).  A later call that is exactly the predicted next line (same y,
+// pointers, width, no state change in between) and whose input bytes still equal the snapshot is
+// served by a memcpy; anything else drops the stripes and starts over from the caller's registers.
+// Lines the caller has not handed over are never written, the seed registers advance per call
+// exactly as before (the stripes ahead run from a speculative copy), so the observable behaviour
+// is unchanged.
 // Lines are only ever read ahead inside rows the caller has PROVEN to own: either it has walked this very buffer
 // (same three line-0 pointers, same width) top to bottom once before -- then the rows up to the height of that walk
 // are known -- or it has told us with vfgs_hip_declare_frame().  A first frame, or a frame in a buffer not seen in the
 // previous walk, is computed line by line.  vfgs_hip_line_lookahead(0) or VFGS_HIP_LINE_LOOKAHEAD=0 turn it off.
 
-constexpr unsigned kMaxAhead = 256;
+// Lines of a stripe computed ahead: about 2 MB of the caller's frame, whole block rows.  Small enough that a stripe's
+// snapshot is still in the host's caches when its lines are compared and handed back, large enough for the link
+// (profiles/r04_line_lookahead_stripe_sweep.log: 0.5 .. 8 MB x 1 or 2 stripes in flight; the calling thread's three passes
+// over every byte -- snapshot, compare, hand back -- are what bounds the call, not the link).
+unsigned lookahead_stripe_lines(const State& s, unsigned nblk)
+{
+	const unsigned sz = s.bs ? 2 : 1;
+	const size_t line_bytes = (size_t)nblk * 16 * sz + 2 * ((size_t)nblk * 16 / s.csubx * sz) / s.csuby;
+	size_t target = 2u << 20;
+#ifdef VFGS_DEV_BUILD      // A/B of the stripe size (tools/dev): VFGS_LA_STRIPE_KB
+	if (const char* e = getenv("VFGS_LA_STRIPE_KB")) target = (size_t)atoi(e) << 10;
+#endif
+	const unsigned n = (unsigned)(target / line_bytes) & ~15u;
+	return std::min(512u, std::max(32u, n));
+}
 
-int line_speculate(State& s, void* Y, void* U, void* V, unsigned y, unsigned width, unsigned n)
+int lookahead_depth()
+{
+#ifdef VFGS_DEV_BUILD      // A/B of the stripes in flight ahead of the one being consumed (tools/dev): VFGS_LA_DEPTH=1..kRing-1
+	if (const char* e = getenv("VFGS_LA_DEPTH")) return std::min(State::LineAhead::kRing - 1, std::max(1, atoi(e)));
+#endif
+	return State::LineAhead::kRing - 1;
+}
+
+// the caller's pointers for line y of the walk in progress (vfgs_main.c:672-681)
+void lookahead_line_ptrs(const State& s, unsigned y, const uint8_t* (&p)[3])
+{
+	const State::LineAhead& la = s.la;
+	const ptrdiff_t crow = (ptrdiff_t)(y / s.csuby) - (ptrdiff_t)(la.base_y / s.csuby);
+	p[0] = la.Y0 + (ptrdiff_t)(y - la.base_y) * la.ypitch;
+	p[1] = la.U0 + crow * la.cpitch;
+	p[2] = la.V0 + crow * la.cpitch;
+}
+
+// every stripe still in flight lands before its buffers are reused (or released)
+int lookahead_drain(State& s)
+{
+	for (State::LineAhead::Slot& sl : s.la.slot)
+	{
+		if (sl.used && !sl.waited) { HIP_TRY(hipEventSynchronize(sl.done)); s.la.stripes_dropped++; }
+		sl.used = sl.waited = false;
+	}
+	return 0;
+}
+
+// Compute lines [y0, y0 + n) ahead of the caller into ring slot k: snapshot of the caller's lines (which it has NOT handed
+// over yet, but has proven to own), upload, kernel from the speculative seed registers, download -- all queued, nothing waited for.
+int lookahead_issue(State& s, int k, unsigned y0, unsigned n)
+{
+	State::LineAhead& la = s.la;
+	State::LineAhead::Slot& sl = la.slot[k];
+	const unsigned sz = s.bs ? 2 : 1;
+	if (sl.used && !sl.waited) HIP_TRY(hipEventSynchronize(sl.done));
+	sl.used = false;
+	if (!la.up)
+	{
+		HIP_TRY(hipStreamCreateWithFlags(&la.up, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&la.run, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&la.down, hipStreamNonBlocking));
+	}
+	if (!sl.done)
+	{
+		HIP_TRY(hipEventCreateWithFlags(&sl.up_done, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&sl.run_done, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+	}
+	const unsigned crow0 = y0 / s.csuby;
+	const unsigned crows = (y0 + n - 1) / s.csuby - crow0 + 1;
+	const unsigned rows[3] = {n, crows, crows};
+	const size_t spitch[3] = {(size_t)la.ypitch, (size_t)la.cpitch, (size_t)la.cpitch};
+	const uint8_t* host[3];
+	lookahead_line_ptrs(s, y0, host);
+	for (int i = 0; i < 3; i++)
+	{
+		const size_t need = (size_t)la.dpitch[i] * rows[i] + 256;
+		if (sl.cap[i] < need)
+		{
+			if (sl.in[i]) HIP_TRY(hipHostFree(sl.in[i]));
+			if (sl.out[i]) HIP_TRY(hipHostFree(sl.out[i]));
+			sl.in[i] = sl.out[i] = nullptr; sl.cap[i] = 0;
+			HIP_TRY(hipHostMalloc((void**)&sl.in[i], need, hipHostMallocDefault));
+			HIP_TRY(hipHostMalloc((void**)&sl.out[i], need, hipHostMallocDefault));
+			sl.cap[i] = need;
+		}
+		if (sl.dcap[i] < need)
+		{
+			if (sl.dev[i]) HIP_TRY(hipFree(sl.dev[i]));
+			sl.dev[i] = nullptr; sl.dcap[i] = 0;
+			HIP_TRY(hipMalloc(&sl.dev[i], need));
+			sl.dcap[i] = need;
+		}
+		for (unsigned r = 0; r < rows[i]; r++)   // snapshot of the caller's lines (also the H2D source)
+			memcpy(sl.in[i] + (size_t)r * la.dpitch[i], host[i] + (size_t)r * spitch[i], la.rowlen[i]);
+		HIP_TRY(hipMemcpyAsync(sl.dev[i], sl.in[i], (size_t)la.dpitch[i] * rows[i], hipMemcpyHostToDevice, la.up));
+	}
+	HIP_TRY(hipEventRecord(sl.up_done, la.up));
+	HIP_TRY(hipStreamWaitEvent(la.run, sl.up_done, 0));
+	// the kernel runs from the registers behind the previous stripe; the caller's registers only move when it hands lines over
+	const uint64_t keep[4] = {s.rnd, s.rnd_up, s.line_rnd, s.line_rnd_up};
+	s.rnd = la.spec[0]; s.rnd_up = la.spec[1]; s.line_rnd = la.spec[2]; s.line_rnd_up = la.spec[3];
+	const int e = run_device(sl.dev[0], sl.dev[1], sl.dev[2], sl.dev[0], sl.dev[1], sl.dev[2], la.width, y0, n, y0, n,
+	                         la.dpitch[0] / sz, la.dpitch[1] / sz, 1, 0, 0, la.run);
+	la.spec[0] = s.rnd; la.spec[1] = s.rnd_up; la.spec[2] = s.line_rnd; la.spec[3] = s.line_rnd_up;
+	s.rnd = keep[0]; s.rnd_up = keep[1]; s.line_rnd = keep[2]; s.line_rnd_up = keep[3];
+	if (e) return e;
+	HIP_TRY(hipEventRecord(sl.run_done, la.run));
+	HIP_TRY(hipStreamWaitEvent(la.down, sl.run_done, 0));
+	for (int i = 0; i < 3; i++)
+		HIP_TRY(hipMemcpyAsync(sl.out[i], sl.dev[i], (size_t)la.dpitch[i] * rows[i], hipMemcpyDeviceToHost, la.down));
+	HIP_TRY(hipEventRecord(sl.done, la.down));
+	sl.used = true; sl.waited = false;
+	sl.y0 = y0; sl.n = n; sl.crow0 = crow0;
+	la.issued_end = y0 + n;
+	la.stripes_issued++;
+	return 0;
+}
+
+// the next stripe(s) down the frame, up to kRing - 1 ahead of the one being consumed
+int lookahead_extend(State& s)
+{
+	State::LineAhead& la = s.la;
+	for (int d = 1; d <= lookahead_depth(); d++)
+	{
+		State::LineAhead::Slot& sl = la.slot[(la.head + d) % State::LineAhead::kRing];
+		if (sl.used && sl.y0 >= la.slot[la.head].y0 + la.slot[la.head].n) continue;     // already ahead of the head
+		if (la.issued_end >= la.frame_end) break;
+		if (int e = lookahead_issue(s, (la.head + d) % State::LineAhead::kRing, la.issued_end, std::min(la.stripe_lines, la.frame_end - la.issued_end)))
+			return e;
+	}
+	return 0;
+}
+
+// hand line y (inside the head stripe, which has landed) to the caller
+void lookahead_serve(State& s, void* Y, void* U, void* V, unsigned y)
+{
+	const State::LineAhead& la = s.la;
+	const State::LineAhead::Slot& sl = la.slot[la.head];
+	const size_t k = y - sl.y0, crow = (size_t)(y / s.csuby - sl.crow0);
+	memcpy(Y, sl.out[0] + k * la.dpitch[0], la.rowlen[0]);
+	if (y % s.csuby == 0)
+	{
+		memcpy(U, sl.out[1] + crow * la.dpitch[1], la.rowlen[1]);
+		memcpy(V, sl.out[2] + crow * la.dpitch[2], la.rowlen[2]);
+	}
+}
+
+// A miss at line y with rows [y, frame_end) proven: start over from the caller's registers.  The first stripe ends on a block
+// row boundary; the next ones are queued behind it right away, so their transfers overlap the caller's walk through this one.
+int line_speculate(State& s, void* Y, void* U, void* V, unsigned y, unsigned width, unsigned frame_end)
 {
 	State::LineAhead& la = s.la;
 	const unsigned sz = s.bs ? 2 : 1;
 	const unsigned nblk = (width + 15) / 16;
-	const unsigned crow0 = y / s.csuby;
-	const unsigned crows = (y + n - 1) / s.csuby - crow0 + 1;
-	const unsigned rows[3] = {n, crows, crows};
-	const size_t spitch[3] = {(size_t)la.ypitch, (size_t)la.cpitch, (size_t)la.cpitch};
-	const uint8_t* host[3] = {(const uint8_t*)Y, (const uint8_t*)U, (const uint8_t*)V};
+	la.valid = false;
+	if (int e = lookahead_drain(s)) return e;
 	for (int i = 0; i < 3; i++)
 	{
 		la.rowlen[i] = (i ? nblk * 16 / s.csubx : nblk * 16) * sz;
 		la.dpitch[i] = (la.rowlen[i] + 255) & ~255u;
-		const size_t need = (size_t)la.dpitch[i] * rows[i] + 256;
-		if (la.cap[i] < need)
-		{
-			if (la.in[i]) HIP_TRY(hipHostFree(la.in[i]));
-			if (la.out[i]) HIP_TRY(hipHostFree(la.out[i]));
-			la.in[i] = la.out[i] = nullptr; la.cap[i] = 0;
-			HIP_TRY(hipHostMalloc((void**)&la.in[i], need, hipHostMallocDefault));
-			HIP_TRY(hipHostMalloc((void**)&la.out[i], need, hipHostMallocDefault));
-			la.cap[i] = need;
-		}
-		if (s.stage_cap[i] < need)
-		{
-			if (s.stage[i]) HIP_TRY(hipFree(s.stage[i]));
-			s.stage[i] = nullptr; s.stage_cap[i] = 0;
-			HIP_TRY(hipMalloc(&s.stage[i], need));
-			s.stage_cap[i] = need;
-		}
-		for (unsigned r = 0; r < rows[i]; r++)   // snapshot of the caller's lines (also the H2D source)
-			memcpy(la.in[i] + (size_t)r * la.dpitch[i], host[i] + (size_t)r * spitch[i], la.rowlen[i]);
-		HIP_TRY(hipMemcpyAsync(s.stage[i], la.in[i], (size_t)la.dpitch[i] * rows[i], hipMemcpyHostToDevice, s.own_stream));
 	}
-	// seeds: the stripe is computed from the current registers, but only line y is committed now
-	const uint64_t r0 = s.rnd, r1 = s.rnd_up, r2 = s.line_rnd, r3 = s.line_rnd_up;
-	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], s.stage[0], s.stage[1], s.stage[2], width, y, n, y, n,
-	                       la.dpitch[0] / sz, la.dpitch[1] / sz, 1, 0, 0, s.own_stream))
-		return e;
-	s.rnd = r0; s.rnd_up = r1; s.line_rnd = r2; s.line_rnd_up = r3;
+	la.width = width;
+	la.base_y = y;
+	la.Y0 = (const uint8_t*)Y; la.U0 = (const uint8_t*)U; la.V0 = (const uint8_t*)V;
+	la.frame_end = frame_end;
+	la.stripe_lines = lookahead_stripe_lines(s, nblk);
+	la.spec[0] = s.rnd; la.spec[1] = s.rnd_up; la.spec[2] = s.line_rnd; la.spec[3] = s.line_rnd_up;
+	la.head = 0;
+	la.issued_end = y;
+	const unsigned first_end = std::min(frame_end, (y & ~15u) + la.stripe_lines);
+	if (int e = lookahead_issue(s, 0, y, first_end - y)) return e;
+	if (int e = lookahead_extend(s)) return e;
+	HIP_TRY(hipEventSynchronize(la.slot[0].done));
+	la.slot[0].waited = true;
+	lookahead_serve(s, Y, U, V, y);
 	advance_seeds(s, y, 1, nblk, y);
-	for (int i = 0; i < 3; i++)
-		HIP_TRY(hipMemcpyAsync(la.out[i], s.stage[i], (size_t)la.dpitch[i] * rows[i], hipMemcpyDeviceToHost, s.own_stream));
-	HIP_TRY(hipStreamSynchronize(s.own_stream));
-	// hand back line y only
-	memcpy(Y, la.out[0], la.rowlen[0]);
-	if (y % s.csuby == 0)
-	{
-		memcpy(U, la.out[1], la.rowlen[1]);
-		memcpy(V, la.out[2], la.rowlen[2]);
-	}
-	la.valid = n > 1;
 	la.gen = s.gen;
-	la.y0 = y; la.n = n; la.next = y + 1; la.width = width; la.crow0 = crow0;
-	la.Y0 = host[0]; la.U0 = host[1]; la.V0 = host[2];
+	la.next = y + 1;
+	la.valid = la.next < la.frame_end;
 	return 0;
 }
 
@@ -1303,28 +1467,47 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 	const unsigned nblk = (width + 15) / 16;
 	int rc = -1;
 
-	// 1. served from the pre-computed stripe?
+	// 1. served from a stripe computed ahead?
 	if (la.valid)
 	{
-		const unsigned k = y - la.y0;
-		const size_t crow = (size_t)(y / s.csuby - la.crow0);
-		const bool predicted = la.gen == s.gen && y == la.next && width == la.width &&
-		                       cY == la.Y0 + (ptrdiff_t)k * la.ypitch &&
-		                       cU == la.U0 + (ptrdiff_t)crow * la.cpitch && cV == la.V0 + (ptrdiff_t)crow * la.cpitch;
-		const bool chroma = (y % s.csuby) == 0;
-		if (predicted && !memcmp(cY, la.in[0] + (size_t)k * la.dpitch[0], la.rowlen[0]) &&
-		    (!chroma || (!memcmp(cU, la.in[1] + crow * la.dpitch[1], la.rowlen[1]) &&
-		                 !memcmp(cV, la.in[2] + crow * la.dpitch[2], la.rowlen[2]))))
+		bool hit = la.gen == s.gen && y == la.next && width == la.width;
+		if (hit)
 		{
-			memcpy(Y, la.out[0] + (size_t)k * la.dpitch[0], la.rowlen[0]);
-			if (chroma)
+			const uint8_t* want[3];
+			lookahead_line_ptrs(s, y, want);
+			hit = cY == want[0] && cU == want[1] && cV == want[2];
+		}
+		if (hit && y == la.slot[la.head].y0 + la.slot[la.head].n)
+		{
+			// the walk enters the next stripe: the slot behind it is free for the stripe after the ones in flight
+			const int nh = (la.head + 1) % State::LineAhead::kRing;
+			hit = la.slot[nh].used && la.slot[nh].y0 == y;
+			if (hit)
 			{
-				memcpy(U, la.out[1] + crow * la.dpitch[1], la.rowlen[1]);
-				memcpy(V, la.out[2] + crow * la.dpitch[2], la.rowlen[2]);
+				la.slot[la.head].used = false;
+				la.head = nh;
+				if (int e = lookahead_extend(s)) return e;
 			}
+		}
+		if (hit)
+		{
+			State::LineAhead::Slot& sl = la.slot[la.head];
+			if (!sl.waited)
+			{
+				HIP_TRY(hipEventSynchronize(sl.done));
+				sl.waited = true;
+			}
+			const size_t k = y - sl.y0, crow = (size_t)(y / s.csuby - sl.crow0);
+			const bool chroma = (y % s.csuby) == 0;
+			hit = !memcmp(cY, sl.in[0] + k * la.dpitch[0], la.rowlen[0]) &&
+			      (!chroma || (!memcmp(cU, sl.in[1] + crow * la.dpitch[1], la.rowlen[1]) && !memcmp(cV, sl.in[2] + crow * la.dpitch[2], la.rowlen[2])));
+		}
+		if (hit)
+		{
+			lookahead_serve(s, Y, U, V, y);
 			advance_seeds(s, y, 1, nblk, y);
 			la.next = y + 1;
-			if (la.next == la.y0 + la.n)
+			if (la.next >= la.frame_end)
 				la.valid = false;
 			rc = 0;
 		}
@@ -1363,12 +1546,10 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 
 		// 3. compute: this line alone, or this line plus the lines the caller is about to hand over (never beyond
 		// the rows it has proven to own)
-		unsigned n = 1;
 		const unsigned sz = s.bs ? 2 : 1;
 		const size_t ylen = (size_t)nblk * 16 * sz, clen = (size_t)nblk * 16 / s.csubx * sz;
-		if (la.ypitch >= (ptrdiff_t)ylen && la.cpitch >= (ptrdiff_t)clen && width > 128 && la.frame_h > y)
-			n = std::min(la.frame_h - y, kMaxAhead);
-		rc = (n > 1) ? line_speculate(s, Y, U, V, y, width, n) : run_host(Y, U, V, y, width, 1, 0, 0);
+		const bool ahead = la.ypitch >= (ptrdiff_t)ylen && la.cpitch >= (ptrdiff_t)clen && width > 128 && la.frame_h > y + 1;
+		rc = ahead ? line_speculate(s, Y, U, V, y, width, la.frame_h) : run_host(Y, U, V, y, width, 1, 0, 0);
 	}
 	la.have_prev = true;
 	la.pY = cY; la.pU = cU; la.pV = cV; la.py = y; la.pwidth = width;
@@ -1535,13 +1716,7 @@ void release_state_impl(State& s)
 	s.lfsr.release();
 	for (int i = 0; i < 3; i++) { if (s.stage[i]) (void)hipFree(s.stage[i]); s.stage[i] = nullptr; s.stage_cap[i] = 0; }
 	s.pipe.release();
-	for (int i = 0; i < 3; i++)
-	{
-		if (s.la.in[i]) (void)hipHostFree(s.la.in[i]);
-		if (s.la.out[i]) (void)hipHostFree(s.la.out[i]);
-		s.la.in[i] = s.la.out[i] = nullptr; s.la.cap[i] = 0;
-	}
-	s.la.valid = false;
+	s.la.release();
 	if (s.fw_const) (void)hipFree(s.fw_const);
 	if (s.dev_bank) (void)hipFree(s.dev_bank);
 	if (s.dev_raw) (void)hipFree(s.dev_raw);
