@@ -215,8 +215,9 @@ int vfgs_hip_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, c
 
 /* What the most recent grain launch of this process (primary device) actually dispatched -- so that a benchmark labels
  * its numbers with the kernel that ran instead of the kernel it expects.  `kernel` is the instantiation's name as the
- * profiler prints it (e.g. "grain_rw_kernel<10,2,2,false,false,true,false>": depth, chroma subsampling x / y,
- * 8-bit destination of a 10-bit path, luma one-pattern form, chroma one-pattern form, rows walked in parts).  Returns 0, or -1 when nothing has been launched yet. */
+ * profiler prints it (e.g. "grain_rw_kernel<10,2,2,false,false,true,false,false>": depth, chroma subsampling
+ * x / y, 8-bit destination of a 10-bit path, luma one-pattern form, chroma one-pattern form, rows walked in parts,
+ * persistent luma workgroups).  Returns 0, or -1 when nothing has been launched yet. */
 typedef struct vfgs_hip_launch_info {
 	int depth, csubx, csuby;          /* sample depth and chroma format the launch was compiled for */
 	int out8;                         /* 1: 10-bit source narrowed to 8 bit in the store */
@@ -228,6 +229,7 @@ typedef struct vfgs_hip_launch_info {
 	int rows_per_wave[2];             /* luma, chroma: rows of one block row a wave walks */
 	int positions_per_row[2];         /* luma, chroma: 1 KiB wave accesses per row */
 	int parts_per_row;                /* passes over the block-parameter table a row needs (1 up to 512 blocks = 8192 samples per row) */
+	int persistent_luma_workgroups;   /* 0, or the number of luma workgroups that share the launch's luma tasks (general-form luma of small pictures) */
 	int waves_per_workgroup;
 	int lds_bytes_per_workgroup;
 	unsigned long long launches;      /* grain launches of this process so far */

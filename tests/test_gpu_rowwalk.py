@@ -98,7 +98,8 @@ def test_widest_row_of_the_parameter_table_and_one_block_more(hip, width, parts)
     assert d.download().equal_all(want)
     assert hip.seed_state() == ora.seed_state()
     info = hip.last_launch_info()
-    assert info["parts_per_row"] == parts and info["kernel"].endswith(",true>" if parts > 1 else ",false>"), info
+    wide_flag = info["kernel"].rstrip(">").split(",")[-2]       # grain_rw_kernel<depth, subx, suby, out8, oney, onec, WIDE, persist>
+    assert info["parts_per_row"] == parts and wide_flag == ("true" if parts > 1 else "false"), info
 
 
 WIDE_FORMATS = ["fgs_sei_10_420", "fgs_afgs1_test1_8_420", "fgs_sei_8_420", "fgs_afgs1_test1_8_444", "fgs_sei_10_422", "fgs_sei_10_444",
@@ -308,3 +309,74 @@ def test_fused_8bit_output_full_size_batches(hip, name, w, h):
     ora, (depth, sx, sy) = program(hip, name)
     frames, _ = T.lcg_frames(w, h, depth, sx, sy, 3)
     copy8_case(hip, ora, frames)
+
+
+def batch_case(hip, ora, frames, part=None, out_of_place=False):
+    """frames (equal geometry) in ONE launch through the batch entry points; every plane byte against the oracle."""
+    import torch
+    f0 = frames[0]
+    n, sz = len(frames), f0.Y.itemsize
+    want = [x.copy() for x in frames]
+    for x in want:
+        ora.add_grain_frame(x)
+    Y = torch.from_numpy(np.stack([x.Y for x in frames]).view(np.uint8)).cuda()
+    U = torch.from_numpy(np.stack([x.U for x in frames]).view(np.uint8)).cuda()
+    V = torch.from_numpy(np.stack([x.V for x in frames]).view(np.uint8)).cuda()
+    dY, dU, dV = (torch.zeros_like(Y), torch.zeros_like(U), torch.zeros_like(V)) if out_of_place else (Y, U, V)
+    py, ph = part if part else (0, f0.height)
+    cy = py // f0.suby
+    yo, co = py * f0.stride * sz, cy * f0.cstride * sz
+    if out_of_place:
+        hip.add_grain_copy_dev(Y.data_ptr() + yo, U.data_ptr() + co, V.data_ptr() + co, dY.data_ptr() + yo, dU.data_ptr() + co, dV.data_ptr() + co,
+                               f0.width, f0.height, py, ph, f0.stride, f0.cstride, n, Y[0].numel(), U[0].numel(), stream_ptr())
+    else:
+        hip.add_grain_frames_part_dev(Y.data_ptr() + yo, U.data_ptr() + co, V.data_ptr() + co, f0.width, f0.height, py, ph, f0.stride, f0.cstride,
+                                      n, Y[0].numel(), U[0].numel(), stream_ptr())
+    torch.cuda.synchronize()
+    gy, gu, gv = (t.cpu().numpy().view(f0.dtype) for t in (dY, dU, dV))
+    c0, c1 = py // f0.suby, (py + ph + f0.suby - 1) // f0.suby
+    # (out of place only whole grain blocks reach the destination; in place the stride padding keeps the caller's bytes)
+    yc = (f0.width + 15) // 16 * 16 if out_of_place else f0.stride
+    cc = yc // f0.subx if out_of_place else f0.cstride
+    for i, wf in enumerate(want):
+        assert np.array_equal(gy[i].reshape(wf.Y.shape)[py:py + ph, :yc], wf.Y[py:py + ph, :yc]), i
+        assert np.array_equal(gu[i].reshape(wf.U.shape)[c0:c1, :cc], wf.U[c0:c1, :cc]), i
+        assert np.array_equal(gv[i].reshape(wf.V.shape)[c0:c1, :cc], wf.V[c0:c1, :cc]), i
+        if out_of_place:
+            assert not gy[i].reshape(wf.Y.shape)[:, yc:].any() and not gu[i].reshape(wf.U.shape)[:, cc:].any()
+        if not out_of_place and part:        # rows outside the part are untouched
+            assert np.array_equal(gy[i].reshape(wf.Y.shape)[:py], frames[i].Y[:py]) and np.array_equal(gy[i].reshape(wf.Y.shape)[py + ph:], frames[i].Y[py + ph:])
+    assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_sei_10_444", "fgs_sei_10_422", "fgs_sei_10_440"])
+@pytest.mark.parametrize("w,h,n", [(384, 224, 230), (1000, 70, 640), (136, 33, 1100)])
+def test_persistent_luma_workgroups(hip, name, w, h, n):
+    """General-form luma, launches of several rounds of luma workgroups: P persistent workgroups share the luma tasks (one staging
+    of the table image each, the block parameters per task).  Hundreds of small frames per launch reach that regime with little
+    data: tasks of every frame position, a last block row that is partial (70 = 4 x 16 + 6 lines, 33 = 2 x 16 + 1), workgroups
+    whose last task index falls behind the end, odd heights at 4:2:0; in place, as a stripe of every frame, and out of place."""
+    ora, (depth, sx, sy) = program(hip, name)
+    frames = [garbage_frame(w, h, depth, sx, sy, 1000 + i) for i in range(n)]
+    batch_case(hip, ora, frames)
+    info = hip.last_launch_info()
+    assert info["persistent_luma_workgroups"] > 0 and info["kernel"].endswith(",true>"), info
+    assert info["persistent_luma_workgroups"] <= 4 * hip.device_info()["cu_count"]
+    if h >= 64:
+        ora2, _ = program(hip, name)
+        batch_case(hip, ora2, frames, part=(16, 32))
+        ora3, _ = program(hip, name)
+        batch_case(hip, ora3, frames, out_of_place=True)
+        assert hip.last_launch_info()["persistent_luma_workgroups"] > 0
+
+
+def test_persistence_is_for_general_form_luma_of_small_pictures_only(hip):
+    ora, (depth, sx, sy) = program(hip, "fgs_afgs1_test1_8_420")        # one-pattern luma: never
+    batch_case(hip, ora, [garbage_frame(384, 224, depth, sx, sy, i) for i in range(230)])
+    assert hip.last_launch_info()["persistent_luma_workgroups"] == 0
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")               # few tasks: never
+    batch_case(hip, ora, [garbage_frame(384, 224, depth, sx, sy, i) for i in range(8)])
+    assert hip.last_launch_info()["persistent_luma_workgroups"] == 0
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_8_420")                # 8 bit: the general-form kernels are bound by LDS instructions, not by
+    batch_case(hip, ora, [garbage_frame(384, 224, depth, sx, sy, i) for i in range(230)])   # the staging: -7 % with persistence (profiles/r04_ab2)
+    assert hip.last_launch_info()["persistent_luma_workgroups"] == 0

@@ -29,6 +29,8 @@ CONFIGS = [  # BASELINE.json configs[i]: name, w, h, depth, (subx, suby), trace,
     # experiments: every plane with luma geometry / a one-pattern luma image at the headline size
     ("7680x4320 10-bit 4:4:4 fgs_sei", 7680, 4320, 10, (1, 1), "fgs_sei_10_444", "grain_rw_kernel<10,1,1,...>"),
     ("7680x4320 10-bit 4:2:0 fgs_afgs1_test1", 7680, 4320, 10, (2, 2), "fgs_afgs1_test1_10_420", "grain_rw_kernel<10,2,2,true,true>"),
+    # the mainstream SEI case: several luma patterns (general form) at 2160p
+    ("3840x2160 10-bit 4:2:0 fgs_sei", 3840, 2160, 10, (2, 2), "fgs_sei_10_420", "grain_rw_kernel<10,2,2,...>"),
 ]
 
 

@@ -24,9 +24,9 @@
 #include "vfgs_layout.h"
 
 namespace vfgs {
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, int grid, hipStream_t stream);
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream);
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
-void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide);
+void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
 hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby,
                            bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, hipStream_t stream);
@@ -43,6 +43,9 @@ extern "C" const unsigned char vfgs_fw_blob[], vfgs_fw_blob_end[];
 #ifndef VFGS_RW_MIN_FILL_PCT
 #define VFGS_RW_MIN_FILL_PCT 100  // a launch should fill this share of the chip's wave slots, else its workgroups get half the rows (25 -> 100: single
 #endif                            // frames +2..8 %, 8-frame launches unchanged; 300 loses 10 % at 1080p x 8: profiles/r03_ab40_min_fill.log)
+#ifndef VFGS_PERSIST_MIN_TASKS
+#define VFGS_PERSIST_MIN_TASKS 3  // general-form luma of small pictures: persistent workgroups (one staging of the 36 KB table image for several
+#endif                            // tasks) when every one of them gets at least this many tasks; 0 = never
 #ifndef VFGS_RW_WG_BYTES
 #define VFGS_RW_WG_BYTES 24576 // a workgroup's rows should hold at least this many bytes (where its block row allows; 16 KiB: the same, 48 KiB: -3..-13 %
 #endif                         // at 8 and at 32 frames per launch, profiles/r04_ab1_wg_bytes_vs_batch_and_tiny_launch_floor.log)
@@ -1065,15 +1068,38 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
 	if (per_frame > 0x3fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;
+	// General-form luma of small pictures: a workgroup stages 36 KB of tables for 15-30 KB of samples.  Where a launch holds several
+	// rounds of luma workgroups, P persistent ones share the luma tasks instead (task t -> workgroup t % P, so they sweep the frames
+	// in memory order together); chroma keeps one workgroup per task behind them in the grid.
+	bool persist = false;
+	long grid = per_frame;
+	// (10 bit only: at 8 bit the general-form kernels are bound by their LDS instructions, and confining luma to P < all workgroup
+	// slots costs them 7 %; at 10 bit 1080p gains 6 % at 32 and 64 frames per launch, 2160p nothing: profiles/r04_ab2_persistent_luma.log)
+	if (VFGS_PERSIST_MIN_TASKS > 0 && s.bs == 2 && !wide && !dg.out8 && !s.img_one_y && a.pd[0].wgs > 0 &&
+	    (size_t)vfgs::kWavesPerWG * a.pd[0].rw_rpw * a.pd[0].rowbytes <= (32u << 10))
+	{
+		const long tasks = (long)a.pd[0].wgs * nframes, slots = (long)s.cu_count * 4;     // (general form: four workgroups per CU)
+		const long k = (tasks + slots - 1) / slots;
+		if (k >= VFGS_PERSIST_MIN_TASKS)
+		{
+			const long P = (tasks + k - 1) / k;
+			persist = true;
+			a.persist_wgs = (int)P;
+			a.persist_step_f = (int)(P / a.pd[0].wgs);
+			a.persist_step_r = (int)(P % a.pd[0].wgs);
+			grid = P + 2L * a.pd[1].wgs * nframes;
+			if (grid > 0x7fffffffL) return fail(14, "launch too large");
+		}
+	}
 	// batches of large frames: two frames are swept at the same time (vfgs_kernel.hip grain_rw_kernel)
 #ifdef VFGS_NO_FRONTS
 	a.lfronts = 0;
 #else
 	// (not inside an overlap region: there the second sweep is the launch on the other stream, and four fronts lose 15 %)
 	const bool in_region = g_states[0].ov.active && (stream == g_states[0].ov.s[0] || stream == g_states[0].ov.s[1]);
-	a.lfronts = (nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
+	a.lfronts = (!persist && nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
 #endif
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, (int)per_frame, stream));
+	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, persist, (int)grid, stream));
 	if (&s == &g_states[0])
 	{
 		vfgs_hip_launch_info& li = g_last_launch;
@@ -1092,10 +1118,11 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 			li.positions_per_row[pt] = a.pd[pt].rw_segs;
 		}
 		li.parts_per_row = (int)nparts;
+		li.persistent_luma_workgroups = persist ? a.persist_wgs : 0;
 		li.waves_per_workgroup = vfgs::kWavesPerWG;
 		const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, s.img_one_y, s.img_one_c);
 		li.lds_bytes_per_workgroup = L.lds_bytes + vfgs::kParamBytes;
-		vfgs::describe_launch(li.kernel, sizeof li.kernel, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide);
+		vfgs::describe_launch(li.kernel, sizeof li.kernel, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, persist);
 		g_last_launch_valid = true;
 	}
 	return 0;

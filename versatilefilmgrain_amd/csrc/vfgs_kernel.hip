@@ -408,8 +408,8 @@ __device__ __forceinline__ void store_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v
 //   * OUT8 (10-bit source, 8-bit destination, yuv.c:216-258): out8 = (v + 2) >> 2 is applied to a lane's results, which
 //     halves them (DW = 2 dwords per unit); everything behind the computation -- rotation back, stores, descriptors -- works
 //     on those halves with the destination's own pitches.
-template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE, int NEG, int NARROW, bool OUT8, bool WIDE>
-__device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f, const int r,
+template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE, int NEG, int NARROW, bool OUT8, bool WIDE, bool PERSIST>
+__device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f_in, const int r_in,
                                              const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
 {
 	constexpr int NS = DEPTH == 8 ? 16 : 8;
@@ -430,9 +430,16 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	static_assert(GPP * NU * BPS == kTileBlocks, "a part is a whole number of groups");
 	constexpr uint32_t PT_CUR = IMG_BYTES, PT_UP = IMG_BYTES + kParamTableBytes;
 	static_assert(IMG_BYTES % 16 == 0, "table image in whole 16-byte units");
+	static_assert(!(PERSIST && (WIDE || NARROW != 0)), "persistent workgroups walk ordinary rows");
 	const int pt = comp ? 1 : 0;
 	auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
+	// One TASK = what a workgroup of the non-persistent launch does: the rows of one part of one block row of frame f.  A
+	// persistent workgroup (PERSIST: general-form luma of small pictures, where the 36 KB table image is more than the 15-30 KB
+	// of samples it serves) runs several tasks with ONE staging of the image: only the block parameters are per task (their
+	// LFSR words and the task's first four positions are requested before the workgroup meets at the barrier that frees the
+	// parameter table).
+	auto task = [&](const int f, const int r, const bool first_task) {
 	// ---- the workgroup's place: block row of the stripe, part of it; the wave's rows -------------------------------
 	const int split = r & (pd.rw_splits - 1);
 	const int kbr = uni(r >> pd.rw_lsplits);             // block row inside the stripe
@@ -463,6 +470,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	constexpr int STEP = kWavesPerWG * 64 * 16;
 	constexpr int NIT = (IMG_BYTES + STEP - 1) / STEP;
 	u32x4 tmp[NIT];
+	if (!PERSIST || first_task)
 	{
 		const __amdgpu_buffer_rsrc_t irs = make_rsrc(a.tables + img_off, IMG_BYTES);
 #pragma unroll
@@ -550,11 +558,16 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 			load_seg<LDA>(rs0, lane16 + (u % NARROW) * UB, 0, w[u]);
 		}
 	}
+	if (!PERSIST || first_task)
+	{
 #pragma unroll
-	for (int it = 0; it < NIT; it++)
-		*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
+		for (int it = 0; it < NIT; it++)
+			*(u32x4*)(lds + min((uint32_t)(threadIdx.x * 16 + it * STEP), (uint32_t)(IMG_BYTES - 16))) = tmp[it];
+	}
+	else
+		__syncthreads();       // every wave is done with the previous task's parameter table
 
-	// ---- block parameters of the row's first part (once per workgroup) ---------------------------------------------
+	// ---- block parameters of the row's first part (once per workgroup and task) --------------------------------------
 	param_table(0, wc0, wu0);
 	__syncthreads();
 	// (WIDE is a kernel of its own: the part loop keeps the LFSR descriptors and a few more values alive through the walk, 5-7
@@ -782,6 +795,23 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 #pragma unroll
 	for (int d = 0; d < KD; d++) outp[DW - KD + d] = lane_down(0u, tp[d]);
 	store_unit<DW, STA>(pdst, laned + (NU - 1) * UBD, outp);
+	};     // task
+
+	if constexpr (!PERSIST)
+		task(f_in, r_in, true);
+	else
+	{
+		// my tasks: t, t + P, t + 2 P, ... of the launch's nframes x pd.wgs luma tasks (frame-major: the persistent workgroups sweep
+		// the frames in memory order together); the host passes P as (frames, tasks) so that nothing is divided here
+		int f = f_in, r = r_in;
+		for (bool first_task = true; f < a.nframes; first_task = false)
+		{
+			task(f, r, first_task);
+			f += a.persist_step_f;
+			r += a.persist_step_r;
+			if (r >= pd.wgs) { r -= pd.wgs; f++; }
+		}
+	}
 }
 
 // Waves per SIMD the kernels are allocated for.  The 8-bit all-one-pattern kernels need 97..100 registers, one
@@ -792,7 +822,7 @@ template <int DEPTH, bool ONEY, bool ONEC>
 constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && VFGS_WG_PER_CU == 4) ? 5 : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
 
 // in place or out of place; workgroups numbered frame -> plane -> block row -> part of the block row
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>
 __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC>())) void grain_rw_kernel(const KernelArgs a)
 {
 	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
@@ -805,11 +835,30 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 	// grid: x = (workgroup inside the frame, frame of a group of 2^lfronts frames), y = group of frames.  Large frames are swept
 	// two at a time: the workgroups of frames 2m and 2m + 1 are dealt out alternately (measured: +1.6 % at 4320p, nothing at 2160p;
 	// more than two, or smaller frames: a loss -- profiles/r03_ab18_frame_fronts_in_one_launch.log)
-	const int f = (int)(blockIdx.y << a.lfronts) + (int)(blockIdx.x & ((1u << a.lfronts) - 1));
-	int r = (int)(blockIdx.x >> a.lfronts);
+	int f, r;
+	if constexpr (PERSIST)
+	{
+		// grid: x = [persistent luma workgroups | one workgroup per chroma task, frame-major]; one division per workgroup
+		static_assert(!ONEY && !WIDE, "persistence exists for the general-form luma image");
+		if ((int)blockIdx.x < a.persist_wgs)
+		{
+			f = (int)blockIdx.x / a.pd[0].wgs;
+			r = (int)blockIdx.x - f * a.pd[0].wgs;
+			run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0, OUT8, WIDE, true>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+			return;
+		}
+		const int x = (int)blockIdx.x - a.persist_wgs, per = 2 * a.pd[1].wgs;
+		f = x / per;
+		r = a.pd[0].wgs + (x - f * per);
+	}
+	else
+	{
+		f = (int)(blockIdx.y << a.lfronts) + (int)(blockIdx.x & ((1u << a.lfronts) - 1));
+		r = (int)(blockIdx.x >> a.lfronts);
+	}
 	if (f >= a.nframes) return;
 	if (r < a.pd[0].wgs)
-		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0, OUT8, WIDE>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0, OUT8, WIDE, false>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
@@ -817,45 +866,57 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 		if (comp == 2) r -= a.pd[1].wgs;
 		// horizontally subsampled chroma rows of one or two positions (2 KiB and less: 1080p at 10 bit, 2160p at 8 bit): several rows per group
 		if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 2)
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 2, OUT8, WIDE>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 2, OUT8, WIDE, false>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 		else if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 1)
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 1, OUT8, WIDE>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 1, OUT8, WIDE, false>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 		else
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 0, OUT8, WIDE>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 0, OUT8, WIDE, false>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 	}
 }
 
 // ---------------------------------------------------------------------------------------
 // host-side launcher (called from vfgs_host.cpp)
 
-template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE>
+template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>
 static hipError_t launch_t(const KernelArgs& a, int grid, hipStream_t stream)
 {
-	hipLaunchKernelGGL((grain_rw_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC, WIDE>), dim3((unsigned)grid << a.lfronts, ((unsigned)a.nframes + (1u << a.lfronts) - 1) >> a.lfronts),
-	                   dim3(kWavesPerWG * 64), 0, stream, a);
+	const dim3 g = PERSIST ? dim3((unsigned)grid) : dim3((unsigned)grid << a.lfronts, ((unsigned)a.nframes + (1u << a.lfronts) - 1) >> a.lfronts);
+	hipLaunchKernelGGL((grain_rw_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC, WIDE, PERSIST>), g, dim3(kWavesPerWG * 64), 0, stream, a);
 	return hipGetLastError();
 }
 
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
-static hipError_t launch_form(const KernelArgs& a, bool oney, bool onec, bool wide, int grid, hipStream_t stream)
+static hipError_t launch_form(const KernelArgs& a, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
 {
-	if (wide) return (oney || onec) ? hipErrorInvalidValue : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, true>(a, grid, stream);
-	if (oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, true, false>(a, grid, stream);
-	if (oney) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, false, false>(a, grid, stream);
-	if (onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, false>(a, grid, stream);
-	return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, false>(a, grid, stream);
+	if (wide) return (oney || onec || persist) ? hipErrorInvalidValue : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, true, false>(a, grid, stream);
+	if constexpr (!OUT8 && DEPTH == 10)     // (the host asks for persistence at 10 bit only)
+	{
+		if (persist)
+		{
+			if (oney) return hipErrorInvalidValue;
+			return onec ? launch_t<DEPTH, CSUBX, CSUBY, false, false, true, false, true>(a, grid, stream)
+			            : launch_t<DEPTH, CSUBX, CSUBY, false, false, false, false, true>(a, grid, stream);
+		}
+	}
+	else if (persist) return hipErrorInvalidValue;
+	if (oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, true, false, false>(a, grid, stream);
+	if (oney) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, false, false, false>(a, grid, stream);
+	if (onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, false, false>(a, grid, stream);
+	return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, false, false>(a, grid, stream);
 }
 
 // out8: the destination holds 8-bit samples of a 10-bit path; oney / onec: the image holds the one-pattern form for luma /
-// chroma (vfgs_layout.h); wide: rows of more than kTileBlocks blocks (general form only); grid: workgroups per frame
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, int grid, hipStream_t stream)
+// chroma (vfgs_layout.h); wide: rows of more than kTileBlocks blocks (general form only); persist: a.persist_wgs luma workgroups
+// share the launch's luma tasks (general-form luma, not wide, not out8), grid = persist_wgs + all chroma tasks; else grid =
+// workgroups per frame
+hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
 {
 	if ((out8 && depth != 10) || wide != (a.nblk > kTileBlocks)) return hipErrorInvalidValue;
-#define VFGS_CASE(D, X, Y)                                                                                         \
-	if (depth == D && csubx == X && csuby == Y)                                                                    \
-	{                                                                                                              \
-		if constexpr (D == 10) { if (out8) return launch_form<D, X, Y, true>(a, oney, onec, wide, grid, stream); } \
-		return launch_form<D, X, Y, false>(a, oney, onec, wide, grid, stream);                                     \
+#define VFGS_CASE(D, X, Y)                                                                                                  \
+	if (depth == D && csubx == X && csuby == Y)                                                                             \
+	{                                                                                                                       \
+		if constexpr (D == 10) { if (out8) return launch_form<D, X, Y, true>(a, oney, onec, wide, persist, grid, stream); } \
+		return launch_form<D, X, Y, false>(a, oney, onec, wide, persist, grid, stream);                                     \
 	}
 	VFGS_CASE(10, 2, 2) VFGS_CASE(10, 2, 1) VFGS_CASE(10, 1, 1) VFGS_CASE(10, 1, 2)
 	VFGS_CASE(8, 2, 2) VFGS_CASE(8, 2, 1) VFGS_CASE(8, 1, 1) VFGS_CASE(8, 1, 2)
@@ -864,10 +925,10 @@ hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bo
 }
 
 // the name of the instantiation launch_grain() dispatches for these arguments, as the profiler prints it (vfgs_hip_last_launch_info)
-void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide)
+void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist)
 {
 	auto b = [](bool v) { return v ? "true" : "false"; };
-	snprintf(out, n, "grain_rw_kernel<%d,%d,%d,%s,%s,%s,%s>", depth, csubx, csuby, b(out8), b(oney), b(onec), b(wide));
+	snprintf(out, n, "grain_rw_kernel<%d,%d,%d,%s,%s,%s,%s,%s>", depth, csubx, csuby, b(out8), b(oney), b(onec), b(wide), b(persist));
 }
 
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec) { return image_layout(csubx, csuby, oney, onec); }

@@ -38,7 +38,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 // developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
 #if !defined(VFGS_DEV_BUILD)
 #if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
-    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT)
+    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS)
 #error "libvfgs_hip: a tuning knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
 #endif
@@ -155,6 +155,8 @@ struct KernelArgs {
 	int nbrows;               // block rows the stripe touches
 	int nframes;
 	int lfronts;              // log2 of the frames of a batch that are swept at the same time (their workgroups are dealt out in turn)
+	int persist_wgs;          // PERSIST kernels: P luma workgroups share the launch's nframes x pd[0].wgs luma tasks (task t -> workgroup t % P) ...
+	int persist_step_f, persist_step_r;   // ... and P = persist_step_f * pd[0].wgs + persist_step_r: what a workgroup advances by
 	uint32_t lo2[2], hi2[2];  // clip bounds in sample units (I_min<<bs ...) in both halves of a dword, per plane type (vfgs_hw.c:264-267)
 };
 
