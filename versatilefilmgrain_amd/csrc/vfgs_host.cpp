@@ -44,8 +44,12 @@ extern "C" const unsigned char vfgs_fw_blob[], vfgs_fw_blob_end[];
 #define VFGS_RW_MIN_FILL_PCT 100  // a launch should fill this share of the chip's wave slots, else its workgroups get half the rows (25 -> 100: single
 #endif                            // frames +2..8 %, 8-frame launches unchanged; 300 loses 10 % at 1080p x 8: profiles/r03_ab40_min_fill.log)
 #ifndef VFGS_PERSIST_MIN_TASKS
-#define VFGS_PERSIST_MIN_TASKS 3  // general-form luma of small pictures: persistent workgroups (one staging of the 36 KB table image for several
-#endif                            // tasks) when every one of them gets at least this many tasks; 0 = never
+#define VFGS_PERSIST_MIN_TASKS 2  // general-form luma of small pictures: persistent workgroups (one staging of the 36 KB table image for several
+#endif                            // tasks) when every one of them gets at least this many tasks; 0 = never (2 instead of 3: 1080p x 8 +3 %,
+                                  // profiles/r04_ab3_persistence_at_4320p_and_two_tasks.log)
+#ifndef VFGS_PERSIST_MAX_WG_KB
+#define VFGS_PERSIST_MAX_WG_KB 32 // ... and only for luma workgroups of at most this many KB of samples (4320p, 60 KB: no gain at 8, -1 % at 16 frames)
+#endif
 #ifndef VFGS_RW_WG_BYTES
 #define VFGS_RW_WG_BYTES 24576 // a workgroup's rows should hold at least this many bytes (where its block row allows; 16 KiB: the same, 48 KiB: -3..-13 %
 #endif                         // at 8 and at 32 frames per launch, profiles/r04_ab1_wg_bytes_vs_batch_and_tiny_launch_floor.log)
@@ -1076,7 +1080,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	// (10 bit only: at 8 bit the general-form kernels are bound by their LDS instructions, and confining luma to P < all workgroup
 	// slots costs them 7 %; at 10 bit 1080p gains 6 % at 32 and 64 frames per launch, 2160p nothing: profiles/r04_ab2_persistent_luma.log)
 	if (VFGS_PERSIST_MIN_TASKS > 0 && s.bs == 2 && !wide && !dg.out8 && !s.img_one_y && a.pd[0].wgs > 0 &&
-	    (size_t)vfgs::kWavesPerWG * a.pd[0].rw_rpw * a.pd[0].rowbytes <= (32u << 10))
+	    (size_t)vfgs::kWavesPerWG * a.pd[0].rw_rpw * a.pd[0].rowbytes <= ((size_t)VFGS_PERSIST_MAX_WG_KB << 10))
 	{
 		const long tasks = (long)a.pd[0].wgs * nframes, slots = (long)s.cu_count * 4;     // (general form: four workgroups per CU)
 		const long k = (tasks + slots - 1) / slots;
