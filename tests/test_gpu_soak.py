@@ -21,6 +21,12 @@ CASES = [
     ("fgs_afgs1_test1_8_444", 3840, 2160, 2, "frames"),  # BASELINE config 4
     ("fgs_afgs1_test1_8_420", 3840, 2160, 2, "frames"),  # the mainstream AFGS1 case (8-bit 4:2:0, vfgs_hw.c:352-362)
     ("fgs_sei_8_420", 3840, 2160, 1, "frames"),          # 8-bit 4:2:0 with per-sample pattern selection
+    # round 4: the persistent luma workgroups at full-chip scale (the timed shapes of bench.py's `configs` leg and of the 2160p SEI case)
+    ("fgs_sei_10_420", 1920, 1080, 2, "frames32"),       # BASELINE config 1 at 32 frames per launch: 5 tasks per persistent workgroup
+    ("fgs_sei_10_420", 1920, 1080, 3, "frames"),         # ... at 8: two tasks each
+    ("fgs_sei_10_420", 3840, 2160, 1, "frames"),         # general-form luma at 2160p: 5 tasks each
+    ("fgs_sei_10_420", 1920, 1080, 2, "frames32_region"),  # ... inside an overlap region (two persistent launches at a time)
+    ("fgs_sei_ar_test1_10_420", 3840, 2160, 1, "copy8_8"),  # fused 8-bit output, one-pattern forms, the timed shape
 ]
 
 
@@ -39,17 +45,23 @@ def test_queued_full_size_batches_equal_oracle(name, w, hh, launches, entry):
     dt = torch.int16 if depth > 8 else torch.uint8
     npd = np.uint16 if depth > 8 else np.uint8
     sz = 2 if depth > 8 else 1
-    batch = 3 if entry in ("part3", "copy3") else 8
+    batch = 3 if entry in ("part3", "copy3") else (32 if entry.startswith("frames32") else 8)
     stride, cstride = w, w // sx
     g = torch.Generator(device="cuda").manual_seed(11)
     mk = lambda r, c: torch.randint(0, 1 << depth, (batch, r, c), dtype=torch.int32, device="cuda", generator=g).to(dt)
     sets = [(mk(hh, stride), mk(hh // sy, cstride), mk(hh // sy, cstride)) for _ in range(launches)]
     src = [tuple(t.cpu().numpy().view(npd) for t in s_) for s_ in sets]
     torch.cuda.synchronize()
-    if entry == "part_region":
+    if entry in ("part_region", "frames32_region"):
         h.overlap_begin(st)
+    out8 = []
     for Y, U, V in sets:      # all launches queued back to back, nothing in between
-        if entry == "copy3":
+        if entry == "copy8_8":
+            d8 = tuple(torch.zeros(t.shape, dtype=torch.uint8, device="cuda") for t in (Y, U, V))
+            h.add_grain_copy8_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), d8[0].data_ptr(), d8[1].data_ptr(), d8[2].data_ptr(), w, hh, 0, hh,
+                                  stride, cstride, stride, cstride, batch, Y[0].numel() * sz, U[0].numel() * sz, d8[0][0].numel(), d8[1][0].numel(), st)
+            out8.append(d8)
+        elif entry == "copy3":
             dst = tuple(torch.zeros_like(t) for t in (Y, U, V))
             h.add_grain_copy_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), dst[0].data_ptr(), dst[1].data_ptr(), dst[2].data_ptr(), w, hh, 0, hh,
                                  stride, cstride, batch, Y[0].numel() * sz, U[0].numel() * sz, st)
@@ -62,16 +74,22 @@ def test_queued_full_size_batches_equal_oracle(name, w, hh, launches, entry):
         else:
             h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, stride, cstride, batch,
                                    Y[0].numel() * sz, U[0].numel() * sz, st)
-    if entry == "part_region":
+    if entry in ("part_region", "frames32_region"):
         h.overlap_end(st)
     torch.cuda.synchronize()
+    if entry.startswith("frames") and name == "fgs_sei_10_420" and w <= 3840:
+        assert h.last_launch_info()["persistent_luma_workgroups"] > 0
     bad = []
     for li, ((Y, U, V), (sY, sU, sV)) in enumerate(zip(sets, src)):
         gY, gU, gV = (t.cpu().numpy().view(npd) for t in (Y, U, V))
+        if out8:
+            gY, gU, gV = (t.cpu().numpy() for t in out8[li])
         for f in range(batch):
             fr = T.Frame(w, hh, depth, sx, sy, stride=stride, cstride=cstride)
             fr.Y[:hh], fr.U[:hh // sy], fr.V[:hh // sy] = sY[f], sU[f], sV[f]
             ora.add_grain_frame(fr)
+            if out8:      # yuv_to_8bit (yuv.c:216-258)
+                fr.Y[...], fr.U[...], fr.V[...] = (fr.Y + 2) >> 2, (fr.U + 2) >> 2, (fr.V + 2) >> 2
             if not (np.array_equal(fr.Y[:hh], gY[f]) and np.array_equal(fr.U[:hh // sy], gU[f]) and np.array_equal(fr.V[:hh // sy], gV[f])):
                 bad.append((li, f))
     assert not bad, f"frames (launch, index) that differ from the oracle: {bad}"
