@@ -2,6 +2,7 @@
 # Developer helper for gpurun: the default bench line + rocprofv3 kernel stats + PMC traffic of the SAME command.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+rm -rf gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq gpurun_out/prof_lds     # (stale passes of earlier calls must not be summarised)
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_kt -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-ceiling --no-parity --no-region --no-configs > $GRAFT_REPO_ROOT/gpurun_out/prof_kt.log 2>&1
