@@ -1068,7 +1068,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.up_bit0 = (uint32_t)(first_up - s.lfsr.base_bit());
 	a.frame_bit_step = nframes > 1 ? (uint32_t)(second_cur - first_cur) : 0;
 
-	// one workgroup per (plane, group of rows, group of tiles), numbered in memory order; not persistent
+	// one workgroup per (frame, plane, block row, part of it), numbered in memory order
 	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
 	if (per_frame > 0x3fffffffL || nframes > 65535) return fail(14, "launch too large");
 	if (per_frame == 0) return 0;

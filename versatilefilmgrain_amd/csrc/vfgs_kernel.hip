@@ -119,9 +119,9 @@ struct LaneMap {
 	__device__ static constexpr int edge_quad(int e) { return PAIR ? 0 : ((e + 1) * BW - (BW - SHIFT)) / 4 - 1; }   // quad left of inner edge e
 };
 
-// A block's parameters in ONE register per run (they stay resident for all rows of a wave; k2, the rounding constants and
-// the relative signs of the edge filter are rebuilt from it for every row with a handful of instructions, which is
-// what keeps the kernel at 6 waves per SIMD):
+// A block's parameters in ONE dword per run (computed once per workgroup and task into the LDS parameter table; a lane reads
+// the 1-3 entries of its runs per position and rebuilds k2, the rounding constants and the relative signs of the edge filter
+// from them with a handful of instructions):
 //   bits 15:0  LDS byte address of bank[.][oy][ox (+ the lane's column for PAIR)][slot 0], row 0 of the block row; one-pattern
 //              form, current row of blocks: of the NEGATED bank if the block's sign is negative (grain_unit)
 //   bit  31    the block's sign is negative
