@@ -444,6 +444,41 @@ def test_line_api_lookahead_sees_late_changes_and_irregular_calls(hip):
         assert hip.seed_state() == ora.seed_state()
 
 
+def test_line_api_lookahead_ring_of_stripes_irregular(hip):
+    """1080p: the rest of a frame is computed ahead in stripes of 352 lines through a ring of three slots (round 4).  Late edits of
+    lines in stripes that are already in flight or back (just before, on and behind stripe boundaries), a line repeated on a
+    boundary, a skip across one, a setter between two stripes -- never observable."""
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_ff_test1_10_420")
+    frames, _ = T.lcg_frames(1920, 1080, depth, sx, sy, 1)
+    rng = np.random.default_rng(9)
+    edits = {3: 351, 349: 352, 350: 704, 351: 353, 600: 1079, 703: 705, 704: 1056, 1000: 1057}    # at line k: rewrite line v (v > k)
+    for fi in range(4):
+        a, b = frames[0].copy(), frames[0].copy()
+        y = 0
+        while y < a.height:
+            for fr, hwimpl in ((a, hip), (b, ora)):
+                hwimpl.add_grain_line(fr.Y[y].ctypes.data, fr.U[y // 2].ctypes.data, fr.V[y // 2].ctypes.data, y, fr.width)
+            assert np.array_equal(a.Y[y], b.Y[y]) and np.array_equal(a.U[y // 2], b.U[y // 2]) and np.array_equal(a.V[y // 2], b.V[y // 2]), (fi, y)
+            if fi >= 1 and y in edits:
+                v = edits[y]
+                patch = rng.integers(0, 1024, a.width).astype(a.dtype)
+                a.Y[v, :a.width] = patch
+                b.Y[v, :a.width] = patch
+                a.U[v // 2, 5:40] = 513
+                b.U[v // 2, 5:40] = 513
+            if fi == 2 and y in (351, 352, 704):           # repeat lines on both sides of a boundary
+                for fr, hwimpl in ((a, hip), (b, ora)):
+                    hwimpl.add_grain_line(fr.Y[y].ctypes.data, fr.U[y // 2].ctypes.data, fr.V[y // 2].ctypes.data, y, fr.width)
+            if fi == 2 and y == 700:                       # skip across a boundary
+                y += 9
+            if fi == 3 and y == 352:                       # a setter between two stripes
+                hip.set_legal_range(1)
+                ora.set_legal_range(1)
+            y += 1
+        assert a.equal_all(b), fi
+        assert hip.seed_state() == ora.seed_state()
+
+
 def test_fuzz_sizes_formats_and_stripes(hip):
     """Randomised geometry: widths that give every segment/tile shape (partial last segment, odd
     number of segments, one- and many-tile rows), heights that are not multiples of 16, uneven

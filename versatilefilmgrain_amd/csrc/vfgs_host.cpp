@@ -1351,7 +1351,25 @@ int lookahead_drain(State& s)
 
 // Compute lines [y0, y0 + n) ahead of the caller into ring slot k: snapshot of the caller's lines (which it has NOT handed
 // over yet, but has proven to own), upload, kernel from the speculative seed registers, download -- all queued, nothing waited for.
+int lookahead_issue_impl(State& s, int k, unsigned y0, unsigned n);
+
 int lookahead_issue(State& s, int k, unsigned y0, unsigned n)
+{
+	const int e = lookahead_issue_impl(s, k, y0, n);
+	if (e)
+	{
+		// part of the stripe may be queued: nothing of it may still be moving when the slot's buffers are used again
+		State::LineAhead& la = s.la;
+		if (la.up) (void)hipStreamSynchronize(la.up);
+		if (la.run) (void)hipStreamSynchronize(la.run);
+		if (la.down) (void)hipStreamSynchronize(la.down);
+		la.slot[k].used = false;
+		la.valid = false;
+	}
+	return e;
+}
+
+int lookahead_issue_impl(State& s, int k, unsigned y0, unsigned n)
 {
 	State::LineAhead& la = s.la;
 	State::LineAhead::Slot& sl = la.slot[k];
