@@ -380,3 +380,15 @@ def test_persistence_is_for_general_form_luma_of_small_pictures_only(hip):
     ora, (depth, sx, sy) = program(hip, "fgs_sei_8_420")                # 8 bit: the general-form kernels are bound by LDS instructions, not by
     batch_case(hip, ora, [garbage_frame(384, 224, depth, sx, sy, i) for i in range(230)])   # the staging: -7 % with persistence (profiles/r04_ab2)
     assert hip.last_launch_info()["persistent_luma_workgroups"] == 0
+
+
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_sei_10_444"])
+def test_fused_8bit_output_with_persistent_luma_workgroups(hip, name):
+    ora, (depth, sx, sy) = program(hip, name)
+    frames = [garbage_frame(384, 224, depth, sx, sy, 300 + i) for i in range(230)]
+    for f in frames:
+        for p in f.planes():
+            np.minimum(p, 0xfffd, out=p)
+    copy8_case(hip, ora, frames)
+    info = hip.last_launch_info()
+    assert info["out8"] == 1 and info["persistent_luma_workgroups"] > 0, info

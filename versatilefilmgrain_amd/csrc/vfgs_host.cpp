@@ -1079,7 +1079,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	long grid = per_frame;
 	// (10 bit only: at 8 bit the general-form kernels are bound by their LDS instructions, and confining luma to P < all workgroup
 	// slots costs them 7 %; at 10 bit 1080p gains 6 % at 32 and 64 frames per launch, 2160p nothing: profiles/r04_ab2_persistent_luma.log)
-	if (VFGS_PERSIST_MIN_TASKS > 0 && s.bs == 2 && !wide && !dg.out8 && !s.img_one_y && a.pd[0].wgs > 0 &&
+	if (VFGS_PERSIST_MIN_TASKS > 0 && s.bs == 2 && !wide && !s.img_one_y && a.pd[0].wgs > 0 &&
 	    (size_t)vfgs::kWavesPerWG * a.pd[0].rw_rpw * a.pd[0].rowbytes <= ((size_t)VFGS_PERSIST_MAX_WG_KB << 10))
 	{
 		const long tasks = (long)a.pd[0].wgs * nframes, slots = (long)s.cu_count * 4;     // (general form: four workgroups per CU)

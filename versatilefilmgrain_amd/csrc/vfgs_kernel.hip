@@ -889,13 +889,13 @@ template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
 static hipError_t launch_form(const KernelArgs& a, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
 {
 	if (wide) return (oney || onec || persist) ? hipErrorInvalidValue : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, true, false>(a, grid, stream);
-	if constexpr (!OUT8 && DEPTH == 10)     // (the host asks for persistence at 10 bit only)
+	if constexpr (DEPTH == 10)     // (the host asks for persistence at 10 bit only)
 	{
 		if (persist)
 		{
 			if (oney) return hipErrorInvalidValue;
-			return onec ? launch_t<DEPTH, CSUBX, CSUBY, false, false, true, false, true>(a, grid, stream)
-			            : launch_t<DEPTH, CSUBX, CSUBY, false, false, false, false, true>(a, grid, stream);
+			return onec ? launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, false, true>(a, grid, stream)
+			            : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, false, true>(a, grid, stream);
 		}
 	}
 	else if (persist) return hipErrorInvalidValue;
@@ -907,7 +907,7 @@ static hipError_t launch_form(const KernelArgs& a, bool oney, bool onec, bool wi
 
 // out8: the destination holds 8-bit samples of a 10-bit path; oney / onec: the image holds the one-pattern form for luma /
 // chroma (vfgs_layout.h); wide: rows of more than kTileBlocks blocks (general form only); persist: a.persist_wgs luma workgroups
-// share the launch's luma tasks (general-form luma, not wide, not out8), grid = persist_wgs + all chroma tasks; else grid =
+// share the launch's luma tasks (10 bit, general-form luma, not wide), grid = persist_wgs + all chroma tasks; else grid =
 // workgroups per frame
 hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
 {
