@@ -60,4 +60,4 @@ for nm, a, b, src in zip("YUV", got.planes(), want.planes(), f[0].planes()):
             worst = max(byrow, key=lambda k: len(byrow[k]))
             bpu = 16 // a.itemsize
             items = sorted(set((c // (256 * bpu), (c // (64 * bpu)) % 4, (c // bpu) % 64, (c % bpu) * a.itemsize // 4) for c in byrow[worst]))
-            print("  worst row", worst, "(tile, seg, lane, dword):", items)
+            print("  worst row", worst, "(group of four positions, position, lane, dword):", items)
