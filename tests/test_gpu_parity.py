@@ -630,3 +630,28 @@ def test_new_seed_per_frame_queued_behind_a_long_launch(hip):
         ora.add_grain_frame(want)
         assert devs[i].download().equal_all(want), i
     assert hip.seed_state() == ora.seed_state()
+
+
+def test_line_api_frame_height_promised_through_the_environment(hip, monkeypatch):
+    """VFGS_HIP_FRAME_HEIGHT: an unchanged binary's first walk through a buffer is computed ahead too (after the lines that show
+    the pitches); results and registers as ever; a walk in a NEW buffer keeps the promise; without the variable the first walk
+    is line by line (one launch per line)."""
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    w, h = 1920, 540
+    frames, _ = T.lcg_frames(w, h, depth, sx, sy, 3)
+    n0 = hip.last_launch_info()["launches"] if hip.last_launch_info() else 0
+    a, b = frames[0].copy(), frames[0].copy()
+    _line_loop(hip, a, sy)
+    _line_loop(ora, b, sy)
+    assert a.equal_all(b)
+    n1 = hip.last_launch_info()["launches"]
+    assert n1 - n0 >= h            # no promise: a launch per line
+    monkeypatch.setenv("VFGS_HIP_FRAME_HEIGHT", str(h))
+    for f in frames[1:]:           # fresh buffers: never walked before
+        a, b = f.copy(), f.copy()
+        _line_loop(hip, a, sy)
+        _line_loop(ora, b, sy)
+        assert a.equal_all(b)
+        assert hip.seed_state() == ora.seed_state()
+    n2 = hip.last_launch_info()["launches"]
+    assert n2 - n1 < 40, n2 - n1    # two frames of 540 lines: a few single lines + a handful of stripes each

@@ -15,10 +15,11 @@ sys.path.insert(0, str(ROOT / "tests"))
 import vfgs_testlib as T  # noqa: E402
 
 
-def run(exe, w, h, n, inp, out):
+def run(exe, w, h, n, inp, out, env=None):
+    import os
     t0 = time.perf_counter()
     subprocess.run([str(exe), "-w", str(w), "-h", str(h), "-b", "10", "-n", str(n), "-r", "12345", str(inp), str(out)], check=True,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, env=dict(os.environ, **(env or {})))
     return time.perf_counter() - t0
 
 
@@ -26,7 +27,7 @@ def main():
     cli, ref = T.REF_DIR / "vfgs_hip_cli", T.REF_DIR / "vfgs_ref"
     assert cli.exists() and ref.exists(), "oracle/_ref binaries were not prebuilt (make -C oracle ref where /root/reference exists)"
     shm = Path("/dev/shm")
-    for (w, h, n1, n2) in ((1920, 1080, 10, 40), (3840, 2160, 6, 18), (7680, 4320, 3, 9)):
+    for (w, h, n1, n2) in ((1920, 1080, 10, 210), (3840, 2160, 6, 56), (7680, 4320, 3, 15)):
         frames, _ = T.lcg_frames(w, h, 10, 2, 2, 3)
         inp = shm / f"vfgs_cli_in_{w}.yuv"
         with open(inp, "wb") as f:
@@ -37,16 +38,22 @@ def main():
         for name, exe in (("reference", ref), ("hip", cli)):
             out = shm / f"vfgs_cli_out_{name}.yuv"
             run(exe, w, h, n1, inp, out)            # (also warms the page cache)
-            t1 = min(run(exe, w, h, n1, inp, out) for _ in range(2))
             t2 = min(run(exe, w, h, n2, inp, out) for _ in range(2))
             md5[name] = hashlib.md5(out.read_bytes()).hexdigest()
+            t1 = min(run(exe, w, h, n1, inp, out) for _ in range(3))
+            md5[name + "_short"] = hashlib.md5(out.read_bytes()).hexdigest()
             per = (t2 - t1) / (n2 - n1)
             res[f"{name}_ms_per_frame_incl_file_io"] = round(per * 1e3, 2)
             res[f"{name}_frames_per_s"] = round(1 / per, 1)
             res[f"{name}_process_s_for_{n1}_frames"] = round(t1, 2)
+            if name == "hip":
+                # the same unchanged binary with the frame height promised from outside: the first walk is computed ahead too
+                tp = min(run(exe, w, h, n1, inp, out, {"VFGS_HIP_FRAME_HEIGHT": str(h)}) for _ in range(3))
+                res[f"hip_process_s_for_{n1}_frames_with_VFGS_HIP_FRAME_HEIGHT"] = round(tp, 2)
+                md5["hip_promised"] = hashlib.md5(out.read_bytes()).hexdigest()
             out.unlink()
         inp.unlink()
-        res["identical_output"] = md5["reference"] == md5["hip"]
+        res["identical_output"] = md5["reference"] == md5["hip"] and md5["reference_short"] == md5["hip_short"] == md5["hip_promised"]
         res["speedup"] = round(res["reference_ms_per_frame_incl_file_io"] / res["hip_ms_per_frame_incl_file_io"], 1)
         print(json.dumps(res), flush=True)
         if not res["identical_output"]:

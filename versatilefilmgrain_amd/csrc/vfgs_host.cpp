@@ -450,6 +450,8 @@ struct State {
 	// staging for the host-pointer entry points
 	void* stage[3] = {nullptr, nullptr, nullptr};
 	size_t stage_cap[3] = {0, 0, 0};
+	uint8_t* bounce[3] = {nullptr, nullptr, nullptr};   // pinned: small host stripes (single lines) travel through these, never
+	size_t bounce_cap[3] = {0, 0, 0};                   // through the caller's own pages (run_host)
 	hipStream_t own_stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	// frames in host memory, pipelined (vfgs_hip_add_grain_frames_host): a ring of device frames, one stream per stage
@@ -521,6 +523,7 @@ struct State {
 		unsigned frame_h = 0;                 // lines of the buffer the caller has proven to own (see line_call), 0 = unknown
 		const uint8_t *bY = nullptr, *bU = nullptr, *bV = nullptr;   // plane pointers of line 0 of the walk in progress
 		bool declared = false;                // frame_h and the pitches come from vfgs_hip_declare_frame
+		bool from_zero = false;               // the calls since the last line 0 were consecutive lines of one walk
 		// the stripes computed ahead of the caller's walk: a ring of slots, each with pinned snapshots of the caller's lines
 		// (`in`, also the upload source), pinned results (`out`) and a device stripe; upload, kernel and download of a stripe
 		// run on three streams, so the stripes further down the frame travel while the caller consumes this one
@@ -1160,6 +1163,14 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 	                          std::max<size_t>((size_t)cstride * sz, rowlen[2])};
 	uint8_t* host[3] = {(uint8_t*)Y + (size_t)(py - y) * spitch[0], (uint8_t*)U + (size_t)(crow0 - y / s.csuby) * spitch[1],
 	                    (uint8_t*)V + (size_t)(crow0 - y / s.csuby) * spitch[2]};
+	// Small stripes -- above all the single lines of the drop-in call -- go through pinned bounce buffers with two memcpys on
+	// this thread.  Handing the caller's own (pageable) pages to the runtime makes it register them with the GPU, and a
+	// registered frame buffer turns the caller's NEXT fread into / fwrite from it into a crawl: the unchanged reference CLI spent
+	// 1.5 s of system time per three 4320p frames in its own file I/O after a first, line-by-line walk (tools/dev/line_time_shim.c,
+	// profiles/r04_cli_shim_probe.log).  Large stripes keep the direct copies: there the runtime's pin-and-DMA path is the faster one.
+	size_t total = 0;
+	for (int i = 0; i < 3; i++) total += (size_t)dpitch[i] * rows[i];
+	const bool via_bounce = total <= (1u << 20);
 	for (int i = 0; i < 3; i++)
 	{
 		const size_t need = (size_t)dpitch[i] * rows[i] + 256;
@@ -1170,14 +1181,35 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 			HIP_TRY(hipMalloc(&s.stage[i], need));
 			s.stage_cap[i] = need;
 		}
-		HIP_TRY(hipMemcpy2DAsync(s.stage[i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, s.own_stream));
+		if (via_bounce)
+		{
+			if (s.bounce_cap[i] < need)
+			{
+				if (s.bounce[i]) HIP_TRY(hipHostFree(s.bounce[i]));
+				s.bounce[i] = nullptr; s.bounce_cap[i] = 0;
+				HIP_TRY(hipHostMalloc((void**)&s.bounce[i], std::max<size_t>(need, 64u << 10), hipHostMallocDefault));
+				s.bounce_cap[i] = std::max<size_t>(need, 64u << 10);
+			}
+			for (unsigned r = 0; r < rows[i]; r++)
+				memcpy(s.bounce[i] + (size_t)r * dpitch[i], host[i] + (size_t)r * spitch[i], rowlen[i]);
+			HIP_TRY(hipMemcpyAsync(s.stage[i], s.bounce[i], (size_t)dpitch[i] * rows[i], hipMemcpyHostToDevice, s.own_stream));
+		}
+		else
+			HIP_TRY(hipMemcpy2DAsync(s.stage[i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, s.own_stream));
 	}
 	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], s.stage[0], s.stage[1], s.stage[2], width, y, height, py, ph,
 	                       dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, s.own_stream))
 		return e;
 	for (int i = 0; i < 3; i++)
-		HIP_TRY(hipMemcpy2DAsync(host[i], spitch[i], s.stage[i], dpitch[i], rowlen[i], rows[i], hipMemcpyDeviceToHost, s.own_stream));
+	{
+		if (via_bounce) HIP_TRY(hipMemcpyAsync(s.bounce[i], s.stage[i], (size_t)dpitch[i] * rows[i], hipMemcpyDeviceToHost, s.own_stream));
+		else HIP_TRY(hipMemcpy2DAsync(host[i], spitch[i], s.stage[i], dpitch[i], rowlen[i], rows[i], hipMemcpyDeviceToHost, s.own_stream));
+	}
 	HIP_TRY(hipStreamSynchronize(s.own_stream));
+	if (via_bounce)
+		for (int i = 0; i < 3; i++)
+			for (unsigned r = 0; r < rows[i]; r++)
+				memcpy(host[i] + (size_t)r * spitch[i], s.bounce[i] + (size_t)r * dpitch[i], rowlen[i]);
 	return 0;
 }
 
@@ -1585,13 +1617,23 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 			la.frame_h = (cY == la.bY && cU == la.bU && cV == la.bV) ? la.py + 1 : 0;
 		}
 		else if (la.have_prev && !la.declared)
-			la.ypitch = la.cpitch = 0, la.frame_h = 0;
+			la.ypitch = la.cpitch = 0, la.frame_h = 0, la.from_zero = false;
 		if (y == 0)
 		{
 			if (la.declared && !(cY == la.bY && cU == la.bU && cV == la.bV && width == la.pwidth))
 				la.declared = false, la.ypitch = la.cpitch = 0, la.frame_h = 0;      // not the declared frame
 			la.bY = cY; la.bU = cU; la.bV = cV;
+			la.from_zero = true;
 		}
+		// A promise from outside the program, for binaries that cannot be rebuilt with vfgs_hip_declare_frame():
+		// VFGS_HIP_FRAME_HEIGHT=<lines> says that every walk that starts at line 0 goes through planes of at least that many
+		// lines (at the pitches its first lines show).  Looked at on misses only.
+		if (!la.declared && la.frame_h == 0 && la.from_zero && la.ypitch > 0 && la.cpitch > 0)
+			if (const char* e = getenv("VFGS_HIP_FRAME_HEIGHT"))
+			{
+				const long hgt = atol(e);
+				if (hgt > 0 && hgt <= 65536) la.frame_h = (unsigned)hgt;
+			}
 
 		// 3. compute: this line alone, or this line plus the lines the caller is about to hand over (never beyond
 		// the rows it has proven to own)
@@ -1764,6 +1806,7 @@ void release_state_impl(State& s)
 	s.tables_ring.release();
 	s.lfsr.release();
 	for (int i = 0; i < 3; i++) { if (s.stage[i]) (void)hipFree(s.stage[i]); s.stage[i] = nullptr; s.stage_cap[i] = 0; }
+	for (int i = 0; i < 3; i++) { if (s.bounce[i]) (void)hipHostFree(s.bounce[i]); s.bounce[i] = nullptr; s.bounce_cap[i] = 0; }
 	s.pipe.release();
 	s.la.release();
 	if (s.fw_const) (void)hipFree(s.fw_const);
