@@ -38,7 +38,10 @@ int main(int argc, char** argv)
 		const double t0 = now();
 		if (fread(Y, 1, bytes, fi) != bytes) return 2;
 		const double t1 = now();
-		if (!noop) vfgs_add_grain_stripe(Y, U, V, 0, w, h, w, w / 2);
+		const int sl = getenv("PROBE_STRIPE_LINES") ? atoi(getenv("PROBE_STRIPE_LINES")) : h;     /* the frame in stripes of this many lines */
+		if (!noop)
+			for (int y = 0; y < h; y += sl)
+				vfgs_add_grain_stripe(Y + (size_t)y * w, U + (size_t)(y / 2) * (w / 2), V + (size_t)(y / 2) * (w / 2), (unsigned)y, w, (unsigned)(y + sl <= h ? sl : h - y), w, w / 2);
 		const double t2 = now();
 		fwrite(Y, 1, bytes, fo);
 		const double t3 = now();
