@@ -74,6 +74,21 @@ __device__ __forceinline__ int mad_vvv(int x, int y, int c)
 	return r;
 }
 
+// sext(byte B of d) * y.i24: the one-pattern bank holds four pattern bytes per dword; SDWA selects and sign-extends one of them inside
+// the multiply (VOP2), which saves the separate extraction where the value itself is not needed (everywhere but at block edges)
+__device__ __forceinline__ int mul_byte_i24(const int b, uint32_t d, uint32_t y)       // (b is a constant after unrolling: one case survives)
+{
+	int r;
+	switch (b)
+	{
+	case 0: asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(d), "v"(y)); break;
+	case 1: asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(d), "v"(y)); break;
+	case 2: asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(d), "v"(y)); break;
+	default: asm("v_mul_i32_i24_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(d), "v"(y)); break;
+	}
+	return r;
+}
+
 __device__ __forceinline__ int swap_lane_pairs(int v)
 {
 	// quad_perm:[1,0,3,2]: lane 2m <-> lane 2m+1
@@ -187,6 +202,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	}
 	uint32_t e[NS];
 	int P[NS];
+	uint32_t pdw[NQ];        // one-pattern form: the four pattern bytes of quad q as they came out of LDS
 
 	// LUT gather: intensity = sample >> bs, as a uint8 (vfgs_hw.c:157,211); entry address = 4 * intensity | table
 #pragma unroll
@@ -216,7 +232,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	// pattern fetch.  General form: 4 samples x 8 slots = 32 bytes per quad, the sample's slot picked by v_perm_b32.
 	// One-pattern form: 4 samples = one dword (at a 2-byte aligned address where the block offsets are multiples of 2
 	// samples, ALIGN2: cut out of two aligned dwords), each value sign-extended out of its byte.
-	auto fetch4 = [&](uint32_t adq, int q, int (&out)[4]) {
+	auto fetch4 = [&](uint32_t adq, int q, int (&out)[4], uint32_t& raw) {
 		if (ONE)
 		{
 			uint32_t d;
@@ -228,6 +244,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 			}
 			else
 				d = *(const uint32_t*)(lds + adq + M::col(q));
+			raw = d;
 #pragma unroll
 			for (int i = 0; i < 4; i++) out[i] = (int)(d << (24 - 8 * i)) >> 24;
 		}
@@ -242,7 +259,8 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	for (int q = 0; q < NQ; q++)
 	{
 		int v4[4];
-		fetch4(ad[M::run(q)], q, v4);
+		pdw[q] = 0;
+		fetch4(ad[M::run(q)], q, v4, pdw[q]);
 #pragma unroll
 		for (int i = 0; i < 4; i++) P[4 * q + i] = v4[i];
 	}
@@ -254,7 +272,8 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 			const int r = M::run(q);
 			const uint32_t uad = (up.pa[r] & 0xffffu) + uprowoff;
 			int Q[4];
-			fetch4(uad, q, Q);
+			uint32_t rawq;
+			fetch4(uad, q, Q, rawq);
 			const int m = (wcur ^ sg[r]) - sg[r];                            // sign_cur * weight_cur
 			const int usg = (int)up.pa[r] >> 31;
 			const int n = (wup ^ usg) - usg;                                 // sign_up * weight_up
@@ -313,9 +332,24 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	// scale, add, clip (vfgs_hw.c:263-267)
 	// round(scale * P, shift) (vfgs_hw.c:263) = (scale * 2^(16-shift) * P + 2^15) >> 16 exactly; the LUT holds
 	// scale * 2^(16-shift), so the shift is free: the pack below simply takes the high halves
-	auto clip2 = [&](uint32_t v, int p0, int p1, uint32_t e0, uint32_t e1) {
-		const int g0 = mad_i24(p0, e0, 0x8000);
-		const int g1 = mad_i24(p1, e1, 0x8000);
+	// scaled grain of sample i, before the final >> 16: from the value itself where the edge filter may have changed it, straight
+	// from the pattern byte (one-pattern form, no overlap blend) everywhere else
+	auto edge_sample = [](int i) {
+		if (M::PAIR) return i == 0 || i == NS - 1;
+		for (int ed = 0; ed < M::NE; ed++)
+			if (i == 4 * M::edge_quad(ed) + 3 || i == 4 * M::edge_quad(ed) + 4) return true;
+		return false;
+	};
+	int G[NS];
+#pragma unroll
+	for (int i = 0; i < NS; i++)
+	{
+		// (8 bit only: +1..2 % there, 8 VGPRs fewer and no spill left in the all-one-pattern kernels; at 10 bit the same change
+		// lets the compiler reach six waves per SIMD, which these kernels do not like: -1..-2.5 %, profiles/r04_ab5_sdwa_multiply.log)
+		if (DEPTH == 8 && ONE && !OVERLAP && !edge_sample(i)) G[i] = mul_byte_i24(i % 4, pdw[i / 4], e[i]) + 0x8000;
+		else G[i] = mad_i24(P[i], e[i], 0x8000);
+	}
+	auto clip2 = [&](uint32_t v, int g0, int g1) {
 		const uint32_t gp = __builtin_amdgcn_perm((uint32_t)g1, (uint32_t)g0, 0x07060302);
 		if (DEPTH > 8)  // a 16-bit container may hold anything: keep the add inside int16 (result is clipped anyway)
 			v = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, v), __builtin_bit_cast(u16x2, 0x70007000u)));
@@ -328,7 +362,7 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	{
 #pragma unroll
 		for (int d = 0; d < 4; d++)
-			w[d] = clip2(w[d], P[2 * d], P[2 * d + 1], e[2 * d], e[2 * d + 1]);
+			w[d] = clip2(w[d], G[2 * d], G[2 * d + 1]);
 	}
 	else
 	{
@@ -336,8 +370,8 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		for (int d = 0; d < 4; d++)
 		{
 			const uint32_t v01 = __builtin_amdgcn_perm(0, w[d], 0x0c010c00), v23 = __builtin_amdgcn_perm(0, w[d], 0x0c030c02);
-			const uint32_t s01 = clip2(v01, P[4 * d], P[4 * d + 1], e[4 * d], e[4 * d + 1]);
-			const uint32_t s23 = clip2(v23, P[4 * d + 2], P[4 * d + 3], e[4 * d + 2], e[4 * d + 3]);
+			const uint32_t s01 = clip2(v01, G[4 * d], G[4 * d + 1]);
+			const uint32_t s23 = clip2(v23, G[4 * d + 2], G[4 * d + 3]);
 			w[d] = __builtin_amdgcn_perm(s23, s01, 0x06040200);
 		}
 	}
