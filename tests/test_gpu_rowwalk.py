@@ -392,3 +392,35 @@ def test_fused_8bit_output_with_persistent_luma_workgroups(hip, name):
     copy8_case(hip, ora, frames)
     info = hip.last_launch_info()
     assert info["out8"] == 1 and info["persistent_luma_workgroups"] > 0, info
+
+
+def test_fuzz_fused_8bit_output_and_wide_rows(hip):
+    """Randomised geometry for the paths that moved onto the row walk in round 4: the fused 8-bit output (any width / height /
+    10-bit format, one or several frames) and rows walked in parts (random widths above 8192 samples, both depths)."""
+    rng = np.random.default_rng(20241004)
+    names10 = ["fgs_sei_10_420", "fgs_sei_10_422", "fgs_sei_10_444", "fgs_sei_10_440", "fgs_sei_ar_test1_10_420", "fgs_afgs1_test1_10_420"]
+    for it in range(24):
+        name = names10[it % len(names10)]
+        ora, (depth, sx, sy) = program(hip, name)
+        w = int(rng.integers(130, 4200))
+        h = int(rng.integers(16, 120))
+        n = int(rng.integers(1, 4))
+        frames = [garbage_frame(w, h, depth, sx, sy, 7000 + 10 * it + i) for i in range(n)]
+        for f in frames:
+            for p in f.planes():
+                np.minimum(p, 0xfffd, out=p)
+        copy8_case(hip, ora, frames)
+    wide = ["fgs_sei_10_420", "fgs_sei_8_420", "fgs_afgs1_test1_8_444", "fgs_sei_10_444", "fgs_afgs1_test1_8_420", "fgs_sei_ff_test6_8_422"]
+    for it in range(12):
+        name = wide[it % len(wide)]
+        ora, (depth, sx, sy) = program(hip, name)
+        w = int(rng.integers(8193, 24000))
+        h = int(rng.integers(16, 50))
+        f = garbage_frame(w, h, depth, sx, sy, 9000 + it)
+        want = f.copy()
+        ora.add_grain_frame(want)
+        d = DevFrame(f)
+        hip.add_grain_frame_dev(*d.ptrs(), f.width, f.height, f.stride, f.cstride, stream_ptr())
+        assert d.download().equal_all(want), (name, w, h)
+        assert hip.seed_state() == ora.seed_state()
+        assert hip.last_launch_info()["parts_per_row"] == ((w + 15) // 16 + 511) // 512
