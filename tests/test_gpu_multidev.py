@@ -62,6 +62,30 @@ def test_host_frames_split_over_devices(hip, name, width, height, ndev):
     assert hip.seed_state() == ora.seed_state()
 
 
+@pytest.mark.parametrize("name,width,height,nframes", [("fgs_sei_10_420", 7680, 4320, 2), ("fgs_sei_10_420", 416, 136, 4), ("fgs_afgs1_test1_8_420", 1920, 1080, 3)])
+def test_eight_way_split(hip, name, width, height, nframes):
+    """The node the scaling bench runs on has eight GPUs; the one-GPU box cannot hold eight rank PROCESSES (its process guard allows
+    six), but eight replica states of device 0 in one process run the same decomposition with the real kernels: 4320p -> 270 block
+    rows -> stripes of 34,34,34,34,34,34,33,33 rows, 136 lines -> 9 block rows over 8 devices (2,1,1,1,1,1,1,1)."""
+    hip.init_devices([0] * 8)
+    ora, (depth, sx, sy) = program(hip, name)
+    frames = random_frames(nframes, width, height, depth, sx, sy, width + 8)
+    want = [f.copy() for f in frames]
+    for w in want:
+        ora.add_grain_frame(w)
+    hip.add_grain_frames_host([f.Y.ctypes.data for f in frames], [f.U.ctypes.data for f in frames],
+                              [f.V.ctypes.data for f in frames], width, height, frames[0].stride, frames[0].cstride)
+    for i, (f, w) in enumerate(zip(frames, want)):
+        assert f.equal_all(w), (i, name)
+    assert hip.seed_state() == ora.seed_state()
+    f = frames[0]
+    w = f.copy()
+    ora.add_grain_frame(w)
+    hip.add_grain_stripe(f.Y.ctypes.data, f.U.ctypes.data, f.V.ctypes.data, 0, width, height, f.stride, f.cstride)
+    assert f.equal_all(w)
+    assert hip.seed_state() == ora.seed_state()
+
+
 def test_stripes_split_over_devices_and_mix_with_single_device_calls(hip):
     """stripe (2 devices) -> device-pointer frame (primary only) -> new seed -> pipelined frames (2 devices) -> a stripe that
     starts in the middle of a block row -> line calls: one seed sequence, as the oracle's."""
