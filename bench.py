@@ -199,6 +199,7 @@ def bench_configs(h, stream, steps_ms=60.0):
                         "launch_us": round(launch_us, 2), "algorithmic_bytes_per_launch": nbytes, "achieved": round(gbs, 1),
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "mpixels_per_s": round(batch * w * hh / launch_us, 1),
                         "kernel": info["kernel"] if info else None, "workgroups_per_frame": info["workgroups_per_frame"] if info else None,
+                        "persistent_luma_workgroups": info["persistent_luma_workgroups"] if info else None,
                         "parity_checked": bool(parity)})
             del sets
             torch.cuda.empty_cache()
