@@ -116,13 +116,13 @@ def kernel_sha():
 
 
 # BASELINE.json configs[0..3] (configs[4] is the headline workload above): name, w, h, depth, (subx, suby), trace, frames per launch.
-# Every configuration is reported at 8 frames per launch (the headline's batch) and at a batch of about 400 MB -- a launch pays
-# ~5 us of fill, drain and kernel boundary, which is a quarter of a 100 MB launch.
+# Every configuration is reported at 8 frames per launch (the headline's batch) and at a larger batch (1080p: 400 MB, 2160p: 800 MB) -- a
+# launch pays ~5 us of fill, drain and kernel boundary, which is a quarter of a 100 MB launch.
 CONFIGS = [
     ("1920x1080 10-bit 4:2:0, cfg fgs_sei", 1920, 1080, 10, (2, 2), "fgs_sei_10_420", (8, 32)),
     ("1920x1080 10-bit 4:2:0, cfg fgs_sei_ff_test1", 1920, 1080, 10, (2, 2), "fgs_sei_ff_test1_10_420", (8, 32)),
-    ("3840x2160 10-bit 4:2:0, cfg fgs_sei_ar_test1", 3840, 2160, 10, (2, 2), "fgs_sei_ar_test1_10_420", (8,)),
-    ("3840x2160 8-bit 4:4:4, cfg fgs_afgs1_test1", 3840, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", (8,)),
+    ("3840x2160 10-bit 4:2:0, cfg fgs_sei_ar_test1", 3840, 2160, 10, (2, 2), "fgs_sei_ar_test1_10_420", (8, 16)),
+    ("3840x2160 8-bit 4:4:4, cfg fgs_afgs1_test1", 3840, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", (8, 16)),
 ]
 
 
