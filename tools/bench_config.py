@@ -52,11 +52,14 @@ def main():
     ap.add_argument("--single-alloc", action="store_true", help="each set is ONE allocation [Y frames | U frames | V frames] (bench.py's layout)")
     ap.add_argument("--width", type=int, default=0, help="override the picture width (experiments)")
     ap.add_argument("--height", type=int, default=0, help="override the picture height (experiments)")
+    ap.add_argument("--stride", type=int, default=0, help="luma row pitch in samples (default: the width; chroma: stride / subx), inplace mode only (experiments)")
     args = ap.parse_args()
     name, w, hh, depth, (sx, sy), trace, kernel = CONFIGS[args.config]
     if args.width or args.height:
         w, hh = args.width or w, args.height or hh
         name += " [size %dx%d]" % (w, hh)
+    if args.stride:
+        name += " [stride %d]" % args.stride
     import os
     if os.environ.get("VFGS_LIB"):
         hw.load(os.environ["VFGS_LIB"])      # a variant build (tools/gpu_variants.sh)
@@ -65,7 +68,9 @@ def main():
     dt = torch.int16 if depth > 8 else torch.uint8
     sz = 2 if depth > 8 else 1
     g = torch.Generator(device="cuda").manual_seed(3)
-    frame_bytes = sz * (w * hh + 2 * (w // sx) * (hh // sy))
+    ws = args.stride or w          # allocated row length in samples
+    assert ws >= w and (ws == w or args.mode == "inplace")
+    frame_bytes = sz * (ws * hh + 2 * (ws // sx) * (hh // sy))
     pool = max(3, int(1.5e9 // (frame_bytes * args.batch)) + 1)       # cycle through > 1.5 GB: nothing is served by the Infinity Cache
     pool = min(pool, 64)
     if args.pool:
@@ -88,7 +93,7 @@ def main():
             b = torch.randint(0, 1 << depth, (ny + 2 * nc,), dtype=torch.int32, device="cuda", generator=g).to(dt)
             sets.append((b[:ny].view(args.batch, hh, w), b[ny:ny + nc].view(args.batch, hh // sy, w // sx), b[ny + nc:].view(args.batch, hh // sy, w // sx)))
     else:
-        sets = [(mk(hh, w), mk(hh // sy, w // sx), mk(hh // sy, w // sx)) for _ in range(pool)]
+        sets = [(mk(hh, ws), mk(hh // sy, ws // sx), mk(hh // sy, ws // sx)) for _ in range(pool)]
     st = torch.cuda.current_stream().cuda_stream
     extra_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else []
     stream_of = (lambda i: extra_streams[i % len(extra_streams)].cuda_stream) if extra_streams else (lambda i: st)
@@ -102,7 +107,7 @@ def main():
     def step(i):
         Y, U, V = sets[i % pool]
         if args.mode == "inplace":
-            h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, w, w // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, stream_of(i))
+            h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, ws, ws // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, stream_of(i))
             return
         dY, dU, dV = dsts[i % len(dsts)]
         if args.mode == "copy":

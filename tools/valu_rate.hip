@@ -42,6 +42,9 @@ DEFK(pkfma,   "v_pk_fma_f16 %0, %0, %4, %5\n v_pk_fma_f16 %1, %1, %5, %4\n v_pk_
 DEFK(cndmask, "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %5, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %5, vcc\n")
 DEFK(dpp,     "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 DEFK(med3,    "v_med3_i32 %0, %0, %4, %5\n v_med3_i32 %1, %1, %5, %4\n v_med3_i32 %2, %2, %4, %5\n v_med3_i32 %3, %3, %5, %4\n")
+DEFK(mad16,   "v_mad_i32_i16 %0, %0, %4, %5\n v_mad_i32_i16 %1, %1, %5, %4 op_sel:[1,0,0,0]\n v_mad_i32_i16 %2, %2, %4, %5\n v_mad_i32_i16 %3, %3, %5, %4 op_sel:[1,0,0,0]\n")
+DEFK(bfeu,    "v_bfe_u32 %0, %0, 8, 8\n v_bfe_u32 %1, %1, 16, 8\n v_bfe_u32 %2, %2, 8, 8\n v_bfe_u32 %3, %3, 16, 8\n")
+DEFK(lshr,    "v_lshrrev_b32 %0, 24, %0\n v_lshrrev_b32 %1, 24, %1\n v_lshrrev_b32 %2, 24, %2\n v_lshrrev_b32 %3, 24, %3\n")
 DEFK(dot2,    "v_dot2_i32_i16 %0, %4, %5, %0\n v_dot2_i32_i16 %1, %5, %4, %1\n v_dot2_i32_i16 %2, %4, %5, %2\n v_dot2_i32_i16 %3, %5, %4, %3\n")
 DEFK(dot4,    "v_dot4_i32_i8 %0, %4, %5, %0\n v_dot4_i32_i8 %1, %5, %4, %1\n v_dot4_i32_i8 %2, %4, %5, %2\n v_dot4_i32_i8 %3, %5, %4, %3\n")
 
@@ -52,7 +55,7 @@ struct K { const char* name; kfn fn; };
 int main()
 {
 	K ks[] = { E(add), E(and_), E(perm), E(mad24), E(mul24), E(mul24sdwa), E(pkadd), E(pkmax), E(pkmad), E(pkmul), E(pkashr), E(ashr), E(bfe),
-	           E(add3), E(lshladd), E(mullo), E(fma), E(pkfma), E(cndmask), E(dpp), E(med3), E(dot2), E(dot4) };
+	           E(add3), E(lshladd), E(mullo), E(fma), E(pkfma), E(cndmask), E(dpp), E(med3), E(mad16), E(bfeu), E(lshr), E(dot2), E(dot4) };
 	hipDeviceProp_t prop;
 	hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount;
