@@ -153,6 +153,25 @@ int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV,
                                  unsigned nframes, uint64_t y_frame_pitch_bytes, uint64_t c_frame_pitch_bytes,
                                  uint64_t dst_y_frame_pitch_bytes, uint64_t dst_c_frame_pitch_bytes, void* stream);
 
+/* Batch of frames that are NOT equally spaced in memory (a decoder's pool of separately allocated frames; the reference's own
+ * loop hands over one frame per call, vfgs_main.c:771-790): `nframes` equally shaped device-resident frames, frame f's planes at
+ * frames[f].Y / .U / .V (device pointers to line 0, 16-byte aligned), processed as consecutive frames in ONE launch per 32
+ * frames -- results and seed registers are those of `nframes` vfgs_hip_add_grain_frame_dev calls in list order.  The list itself
+ * is host memory, read during the call only (the pointers travel in the kernel arguments: nothing to keep alive, no copy queued
+ * in front of the launch).  A single frame per launch runs at 0.23 (1080p) / 0.49 (2160p) / 0.61 (4320p) of the HBM peak, the
+ * same frames handed over 32 / 16 / 8 at a time at 0.70 / 0.76 / 0.72 (a launch costs 5 us of fill and drain).  All frames of
+ * a call are in flight together: a destination plane may appear only once in the list (refused otherwise), and planes of
+ * different frames must not overlap.  _copy: out of place, src[f] -> dst[f], same geometry (src[f] == dst[f] allowed);
+ * _copy8: 10-bit source, 8-bit destination as vfgs_hip_add_grain_copy8_dev.  A refused call changes nothing. */
+typedef struct vfgs_hip_frame_ptrs { void* Y; void* U; void* V; } vfgs_hip_frame_ptrs;
+int vfgs_hip_add_grain_frame_list_dev(const vfgs_hip_frame_ptrs* frames, unsigned nframes, unsigned width, unsigned height,
+                                      unsigned stride, unsigned cstride, void* stream);
+int vfgs_hip_add_grain_frame_list_copy_dev(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes,
+                                           unsigned width, unsigned height, unsigned stride, unsigned cstride, void* stream);
+int vfgs_hip_add_grain_frame_list_copy8_dev(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes,
+                                            unsigned width, unsigned height, unsigned stride, unsigned cstride,
+                                            unsigned dst_stride, unsigned dst_cstride, void* stream);
+
 /* {rnd, rnd_up, line_rnd, line_rnd_up} as the reference would hold them (vfgs_hw.c:52-55). */
 void vfgs_hip_get_seed_state(uint32_t out[4]);
 
@@ -237,6 +256,7 @@ typedef struct vfgs_hip_launch_info {
 	int lds_bytes_per_workgroup;
 	unsigned long long launches;      /* grain launches of this process so far */
 	char kernel[96];
+	int listed;                       /* 1: the frames' plane pointers came as a list (vfgs_hip_add_grain_frame_list_*) */
 } vfgs_hip_launch_info;
 int vfgs_hip_last_launch_info(vfgs_hip_launch_info* out);
 

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="experiment: issue consecutive launches round-robin on this many streams (they may overlap)")
     ap.add_argument("--pool", type=int, default=0, help="buffer sets cycled through (default: enough for > 1.5 GB)")
     ap.add_argument("--single-alloc", action="store_true", help="each set is ONE allocation [Y frames | U frames | V frames] (bench.py's layout)")
+    ap.add_argument("--list", action="store_true", help="every frame of a launch is an allocation of its own (shuffled order, odd gaps), handed over "
+                                                        "as a list of plane pointers: vfgs_hip_add_grain_frame_list_dev (inplace mode)")
     ap.add_argument("--width", type=int, default=0, help="override the picture width (experiments)")
     ap.add_argument("--height", type=int, default=0, help="override the picture height (experiments)")
     ap.add_argument("--stride", type=int, default=0, help="luma row pitch in samples (default: the width; chroma: stride / subx), inplace mode only (experiments)")
@@ -86,7 +88,22 @@ def main():
             noise = torch.randint(-4, 5, (args.batch, rows, cols), dtype=torch.int32, device="cuda", generator=g)
             return (base + noise).clamp(0, (1 << depth) - 1).to(dt)
         return torch.randint(0, 1 << depth, (args.batch, rows, cols), dtype=torch.int32, device="cuda", generator=g).to(dt)
-    if args.single_alloc:
+    if args.list:
+        assert args.mode == "inplace" and not args.stride
+        import random
+        rnd = random.Random(5)
+        sets, keep = [], []
+        for _ in range(pool):
+            planes = [None] * (3 * args.batch)
+            order = list(range(3 * args.batch))
+            rnd.shuffle(order)
+            for k in order:
+                rows, cols = (hh, w) if k % 3 == 0 else (hh // sy, w // sx)
+                planes[k] = torch.randint(0, 1 << depth, (rows, cols), dtype=torch.int32, device="cuda", generator=g).to(dt)
+                keep.append(torch.empty(rnd.randrange(1, 64) * 4096, dtype=torch.uint8, device="cuda"))      # a gap of odd size behind it
+            sets.append(h.frame_list([(planes[3 * f].data_ptr(), planes[3 * f + 1].data_ptr(), planes[3 * f + 2].data_ptr()) for f in range(args.batch)]))
+            keep.append(planes)
+    elif args.single_alloc:
         sets = []
         for _ in range(pool):
             ny, nc = args.batch * hh * w, args.batch * (hh // sy) * (w // sx)
@@ -105,6 +122,9 @@ def main():
                  torch.zeros((args.batch, hh // sy, w // sx), dtype=ddt, device="cuda")) for _ in range(min(pool, 4))]
 
     def step(i):
+        if args.list:
+            h.add_grain_frame_list_dev(sets[i % pool], w, hh, w, w // sx, stream_of(i))
+            return
         Y, U, V = sets[i % pool]
         if args.mode == "inplace":
             h.add_grain_frames_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, hh, ws, ws // sx, args.batch, Y[0].numel() * sz, U[0].numel() * sz, stream_of(i))
@@ -151,7 +171,7 @@ def main():
     nbytes = (sz + (1 if args.mode == "copy8" else sz)) * samples
     info = h.last_launch_info()
     kernel = info["kernel"] if info else kernel
-    print(json.dumps({"config": args.config, "workload": name, "content": args.content, "mode": args.mode, "streams": args.streams, "overlap_region": bool(args.overlap), "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
+    print(json.dumps({"config": args.config, "workload": name, "content": args.content, "mode": args.mode, "frame_list": bool(args.list), "streams": args.streams, "overlap_region": bool(args.overlap), "kernel": kernel, "frames_per_launch": args.batch, "steps": args.steps,
                       "launch_us": round(launch_us, 2), "host_us_per_call": round(host_us, 2), "us_per_frame": round(us, 3), "algorithmic_bytes_per_frame": int(nbytes),
                       "GBps": round(nbytes / us / 1e3, 1), "frac_of_8TBps": round(nbytes / us / 1e3 / 8000, 4),
                       "Mpixels_per_s": round(w * hh / us, 1), "Msamples_per_s": round(samples / us, 1)}), flush=True)

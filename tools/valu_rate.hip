@@ -15,7 +15,7 @@ __global__ void k_##NAME(uint32_t* out, int iters)                              
 	uint32_t r0 = a, r1 = b, r2 = a ^ b, r3 = a + b;                                                  \
 	for (int i = 0; i < iters; i++)                                                                   \
 	{                                                                                                \
-		asm volatile(REP16(ASM) : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "v"(b), "v"(c), "v"(d)); \
+		asm volatile(REP16(ASM) : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(a), "v"(b), "v"(c), "v"(d) : "vcc", "s10", "s11", "s12", "s13"); \
 	}                                                                                                \
 	out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3;                                   \
 }
@@ -40,6 +40,13 @@ DEFK(mullo,   "v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %5\n v_mul_lo_u32 
 DEFK(fma,     "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %5, %4\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %5, %4\n")
 DEFK(pkfma,   "v_pk_fma_f16 %0, %0, %4, %5\n v_pk_fma_f16 %1, %1, %5, %4\n v_pk_fma_f16 %2, %2, %4, %5\n v_pk_fma_f16 %3, %3, %5, %4\n")
 DEFK(cndmask, "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %5, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %5, vcc\n")
+DEFK(cndmask_s, "v_cndmask_b32_e64 %0, %0, %4, s[10:11]\n v_cndmask_b32_e64 %1, %1, %5, s[10:11]\n v_cndmask_b32_e64 %2, %2, %4, s[10:11]\n v_cndmask_b32_e64 %3, %3, %5, s[10:11]\n")
+DEFK(cndmask_i, "v_cndmask_b32 %0, %4, %5, vcc\n v_cndmask_b32 %1, %5, %4, vcc\n v_cndmask_b32 %2, %4, %5, vcc\n v_cndmask_b32 %3, %5, %4, vcc\n")
+DEFK(bfi,     "v_bfi_b32 %0, %6, %4, %0\n v_bfi_b32 %1, %6, %5, %1\n v_bfi_b32 %2, %6, %4, %2\n v_bfi_b32 %3, %6, %5, %3\n")
+DEFK(cmp,     "v_cmp_gt_i32 vcc, %0, %4\n v_cmp_gt_i32 vcc, %1, %5\n v_cmp_gt_i32 vcc, %2, %4\n v_cmp_gt_i32 vcc, %3, %5\n")
+DEFK(cmp_s,   "v_cmp_gt_i32_e64 s[10:11], %0, %4\n v_cmp_gt_i32_e64 s[12:13], %1, %5\n v_cmp_gt_i32_e64 s[10:11], %2, %4\n v_cmp_gt_i32_e64 s[12:13], %3, %5\n")
+DEFK(cmpcnd,  "v_cmp_gt_i32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %5, vcc\n v_cmp_gt_i32 vcc, %1, %5\n v_cndmask_b32 %1, %1, %4, vcc\n")
+DEFK(minmax,  "v_max_i32 %0, %0, %4\n v_min_i32 %1, %1, %5\n v_max_i32 %2, %2, %4\n v_min_i32 %3, %3, %5\n")
 DEFK(dpp,     "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 DEFK(med3,    "v_med3_i32 %0, %0, %4, %5\n v_med3_i32 %1, %1, %5, %4\n v_med3_i32 %2, %2, %4, %5\n v_med3_i32 %3, %3, %5, %4\n")
 DEFK(mad16,   "v_mad_i32_i16 %0, %0, %4, %5\n v_mad_i32_i16 %1, %1, %5, %4 op_sel:[1,0,0,0]\n v_mad_i32_i16 %2, %2, %4, %5\n v_mad_i32_i16 %3, %3, %5, %4 op_sel:[1,0,0,0]\n")
@@ -55,7 +62,7 @@ struct K { const char* name; kfn fn; };
 int main()
 {
 	K ks[] = { E(add), E(and_), E(perm), E(mad24), E(mul24), E(mul24sdwa), E(pkadd), E(pkmax), E(pkmad), E(pkmul), E(pkashr), E(ashr), E(bfe),
-	           E(add3), E(lshladd), E(mullo), E(fma), E(pkfma), E(cndmask), E(dpp), E(med3), E(mad16), E(bfeu), E(lshr), E(dot2), E(dot4) };
+	           E(add3), E(lshladd), E(mullo), E(fma), E(pkfma), E(cndmask), E(cndmask_s), E(cndmask_i), E(bfi), E(cmp), E(cmp_s), E(cmpcnd), E(minmax), E(dpp), E(med3), E(mad16), E(bfeu), E(lshr), E(dot2), E(dot4) };
 	hipDeviceProp_t prop;
 	hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount;

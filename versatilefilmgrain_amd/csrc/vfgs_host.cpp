@@ -24,7 +24,7 @@
 #include "vfgs_layout.h"
 
 namespace vfgs {
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream);
+hipError_t launch_grain(const KernelArgs& a, const FrameTable* list, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream);
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
 void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
@@ -962,9 +962,11 @@ struct DstGeom {          // destination geometry when it differs from the sourc
 
 int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* dU, void* dV, unsigned width,
                unsigned frame_y, unsigned frame_h, unsigned part_y, unsigned part_h, unsigned stride, unsigned cstride,
-               unsigned nframes, uint64_t ypitch, uint64_t cpitch, hipStream_t stream, DstGeom dg = DstGeom())
+               unsigned nframes, uint64_t ypitch, uint64_t cpitch, hipStream_t stream, DstGeom dg = DstGeom(),
+               const vfgs::FrameTable* list = nullptr)     // list: the planes of the frames (sY.. / dY.. = those of frame 0, the pitches unused)
 {
 	State& s = S();
+	if (list && nframes > (unsigned)vfgs::kListFrames) return fail(19, "internal: a listed launch holds at most %d frames", vfgs::kListFrames);
 	if (int e = ensure_init(-1)) return e;
 	if (int e = check_geometry(s, sY, sU, sV, width, stride, cstride)) return e;
 	if (!dg.out8)
@@ -996,6 +998,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	const int nbr_stripe = (int)(((part_y + part_h - 1) >> 4) - (part_y >> 4) + 1);
 	a.nbrows = nbr_stripe;
 	a.nframes = (int)nframes;
+	a.listed = list ? 1 : 0;
 	a.lo2[0] = (uint32_t)(s.ymin << s.bs) * 0x10001u; a.hi2[0] = (uint32_t)(s.ymax << s.bs) * 0x10001u;
 	a.lo2[1] = (uint32_t)(s.cmin << s.bs) * 0x10001u; a.hi2[1] = (uint32_t)(s.cmax << s.bs) * 0x10001u;
 	// Geometry: a wave streams whole rows (positions = the row's units + the one behind them: the lanes compute bytes shifted
@@ -1106,7 +1109,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	const bool in_region = g_states[0].ov.active && (stream == g_states[0].ov.s[0] || stream == g_states[0].ov.s[1]);
 	a.lfronts = (!persist && nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
 #endif
-	HIP_TRY(vfgs::launch_grain(a, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, persist, (int)grid, stream));
+	HIP_TRY(vfgs::launch_grain(a, list, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, persist, (int)grid, stream));
 	if (&s == &g_states[0])
 	{
 		vfgs_hip_launch_info& li = g_last_launch;
@@ -1116,6 +1119,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		li.depth = 8 + s.bs; li.csubx = s.csubx; li.csuby = s.csuby;
 		li.out8 = dg.out8; li.one_y = s.img_one_y; li.one_c = s.img_one_c;
 		li.in_place = (sY == dY && sU == dU && sV == dV);
+		li.listed = a.listed;
 		li.nframes = (int)nframes;
 		li.workgroups_per_frame = (int)per_frame;
 		li.frames_per_front = 1 << a.lfronts;
@@ -2176,6 +2180,72 @@ int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned wi
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
 	                  y_frame_pitch_bytes, c_frame_pitch_bytes, pick_stream(stream));
+}
+
+// Frames anywhere in device memory (vfgs_hip.h): validated as a whole before anything moves, then launched in chunks of
+// kListFrames frames whose plane pointers travel in the kernel arguments.
+static int run_frame_list(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes, unsigned width, unsigned height,
+                          unsigned stride, unsigned cstride, hipStream_t stream, DstGeom dg)
+{
+	State& s = S();
+	if (int e = ensure_init(-1)) return e;
+	if (nframes == 0) return 0;
+	if (!src || !dst) return fail(18, "frame list: null list");
+	for (unsigned f = 0; f < nframes; f++)
+	{
+		if (!src[f].Y || !src[f].U || !src[f].V || !dst[f].Y || !dst[f].U || !dst[f].V) return fail(18, "frame list: frame %u has a null plane", f);
+		if (int e = check_geometry(s, src[f].Y, src[f].U, src[f].V, width, stride, cstride)) return e;
+		if ((((uintptr_t)dst[f].Y | (uintptr_t)dst[f].U | (uintptr_t)dst[f].V) & 15)) return fail(7, "plane pointers must be 16-byte aligned");
+	}
+	// the frames run concurrently: a destination that appears twice would be a race where consecutive calls are not
+	std::vector<const void*> seen;
+	seen.reserve(3 * (size_t)nframes);
+	for (unsigned f = 0; f < nframes; f++) { seen.push_back(dst[f].Y); seen.push_back(dst[f].U); seen.push_back(dst[f].V); }
+	std::sort(seen.begin(), seen.end());
+	if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return fail(18, "frame list: a destination plane is listed twice");
+	for (unsigned f0 = 0; f0 < nframes; f0 += vfgs::kListFrames)
+	{
+		const unsigned n = std::min<unsigned>(vfgs::kListFrames, nframes - f0);
+		vfgs::FrameTable ft{};
+		for (unsigned k = 0; k < n; k++)
+		{
+			const vfgs_hip_frame_ptrs &a = src[f0 + k], &b = dst[f0 + k];
+			ft.src[0][k] = (const uint8_t*)a.Y; ft.src[1][k] = (const uint8_t*)a.U; ft.src[2][k] = (const uint8_t*)a.V;
+			ft.dst[0][k] = (uint8_t*)b.Y; ft.dst[1][k] = (uint8_t*)b.U; ft.dst[2][k] = (uint8_t*)b.V;
+		}
+		if (int e = run_device(src[f0].Y, src[f0].U, src[f0].V, dst[f0].Y, dst[f0].U, dst[f0].V, width, 0, height, 0, height, stride, cstride,
+		                       n, 0, 0, stream, dg, &ft))
+			return e;
+	}
+	return 0;
+}
+
+int vfgs_hip_add_grain_frame_list_dev(const vfgs_hip_frame_ptrs* frames, unsigned nframes, unsigned width, unsigned height,
+                                      unsigned stride, unsigned cstride, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	return run_frame_list(frames, frames, nframes, width, height, stride, cstride, pick_stream(stream), DstGeom());
+}
+
+int vfgs_hip_add_grain_frame_list_copy_dev(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes, unsigned width,
+                                           unsigned height, unsigned stride, unsigned cstride, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	return run_frame_list(src, dst, nframes, width, height, stride, cstride, pick_stream(stream), DstGeom());
+}
+
+int vfgs_hip_add_grain_frame_list_copy8_dev(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes, unsigned width,
+                                            unsigned height, unsigned stride, unsigned cstride, unsigned dst_stride, unsigned dst_cstride,
+                                            void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	DstGeom dg;
+	dg.out8 = true;
+	dg.stride = dst_stride; dg.cstride = dst_cstride;
+	return run_frame_list(src, dst, nframes, width, height, stride, cstride, pick_stream(stream), dg);
 }
 
 int vfgs_hip_add_grain_frames_host(void* const* Y, void* const* U, void* const* V, unsigned nframes, unsigned width,

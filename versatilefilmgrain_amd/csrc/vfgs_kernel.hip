@@ -443,7 +443,7 @@ __device__ __forceinline__ void store_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v
 //     halves them (DW = 2 dwords per unit); everything behind the computation -- rotation back, stores, descriptors -- works
 //     on those halves with the destination's own pitches.
 template <int DEPTH, int BW, int SUBX, int SUBY, int RS, int IMG_BYTES, bool ONE, int NEG, int NARROW, bool OUT8, bool WIDE, bool PERSIST>
-__device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f_in, const int r_in,
+__device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTable& ft, const PlaneDesc& pd, uint8_t* lds, const int comp, const int f_in, const int r_in,
                                              const uint32_t img_off, const uint32_t bank_off, const uint32_t lut_off, const int lane, const int wave)
 {
 	constexpr int NS = DEPTH == 8 ? 16 : 8;
@@ -562,8 +562,9 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const PlaneDes
 	// operand IS part of what is checked against num_records, so the row offset has to go into the base.)
 	const int tsegs = pd.rw_segs;
 	const int ngroups = (tsegs + NU - 1) / NU;
-	const uint8_t* sbase = a.src[comp] + (uint64_t)f * pd.fpitch;
-	uint8_t* dbase = a.dst[comp] + (uint64_t)f * pd.dfpitch;
+	// (frames at a constant pitch, or a list of frames anywhere: their pointers sit in the kernel arguments, one scalar load)
+	const uint8_t* sbase = a.listed ? ft.src[comp][f] : a.src[comp] + (uint64_t)f * pd.fpitch;
+	uint8_t* dbase = a.listed ? ft.dst[comp][f] : a.dst[comp] + (uint64_t)f * pd.dfpitch;
 	const uint32_t lane16 = (uint32_t)lane * 16;
 	const uint32_t laned = (uint32_t)lane * (4 * DW);    // ... in the destination
 	constexpr uint32_t UB = kMaxUnits * 16, UBD = kMaxUnits * 4 * DW;   // bytes of a position, source / destination
@@ -857,7 +858,7 @@ constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && VFGS_W
 
 // in place or out of place; workgroups numbered frame -> plane -> block row -> part of the block row
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>
-__global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC>())) void grain_rw_kernel(const KernelArgs a)
+__global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC>())) void grain_rw_kernel(const KernelArgs a, const FrameTable ft)
 {
 	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes + kParamBytes];
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 		{
 			f = (int)blockIdx.x / a.pd[0].wgs;
 			r = (int)blockIdx.x - f * a.pd[0].wgs;
-			run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0, OUT8, WIDE, true>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+			run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0, OUT8, WIDE, true>(a, ft, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 			return;
 		}
 		const int x = (int)blockIdx.x - a.persist_wgs, per = 2 * a.pd[1].wgs;
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 	}
 	if (f >= a.nframes) return;
 	if (r < a.pd[0].wgs)
-		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0, OUT8, WIDE, false>(a, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
+		run_plane_rw<DEPTH, 16, 1, 1, L.y_rs, L.y_bytes, ONEY, L.y_neg, 0, OUT8, WIDE, false>(a, ft, a.pd[0], lds, 0, f, r, L.y_off, L.y_bank, 0, lane, wave);
 	else
 	{
 		r -= a.pd[0].wgs;
@@ -900,11 +901,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 		if (comp == 2) r -= a.pd[1].wgs;
 		// horizontally subsampled chroma rows of one or two positions (2 KiB and less: 1080p at 10 bit, 2160p at 8 bit): several rows per group
 		if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 2)
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 2, OUT8, WIDE, false>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 2, OUT8, WIDE, false>(a, ft, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 		else if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 1)
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 1, OUT8, WIDE, false>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 1, OUT8, WIDE, false>(a, ft, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 		else
-			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 0, OUT8, WIDE, false>(a, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
+			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, 0, OUT8, WIDE, false>(a, ft, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 	}
 }
 
@@ -912,45 +913,48 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 // host-side launcher (called from vfgs_host.cpp)
 
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>
-static hipError_t launch_t(const KernelArgs& a, int grid, hipStream_t stream)
+static hipError_t launch_t(const KernelArgs& a, const FrameTable& ft, int grid, hipStream_t stream)
 {
 	const dim3 g = PERSIST ? dim3((unsigned)grid) : dim3((unsigned)grid << a.lfronts, ((unsigned)a.nframes + (1u << a.lfronts) - 1) >> a.lfronts);
-	hipLaunchKernelGGL((grain_rw_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC, WIDE, PERSIST>), g, dim3(kWavesPerWG * 64), 0, stream, a);
+	hipLaunchKernelGGL((grain_rw_kernel<DEPTH, CSUBX, CSUBY, OUT8, ONEY, ONEC, WIDE, PERSIST>), g, dim3(kWavesPerWG * 64), 0, stream, a, ft);
 	return hipGetLastError();
 }
 
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
-static hipError_t launch_form(const KernelArgs& a, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
+static hipError_t launch_form(const KernelArgs& a, const FrameTable& ft, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
 {
-	if (wide) return (oney || onec || persist) ? hipErrorInvalidValue : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, true, false>(a, grid, stream);
+	if (wide) return (oney || onec || persist) ? hipErrorInvalidValue : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, true, false>(a, ft, grid, stream);
 	if constexpr (DEPTH == 10)     // (the host asks for persistence at 10 bit only)
 	{
 		if (persist)
 		{
 			if (oney) return hipErrorInvalidValue;
-			return onec ? launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, false, true>(a, grid, stream)
-			            : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, false, true>(a, grid, stream);
+			return onec ? launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, false, true>(a, ft, grid, stream)
+			            : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, false, true>(a, ft, grid, stream);
 		}
 	}
 	else if (persist) return hipErrorInvalidValue;
-	if (oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, true, false, false>(a, grid, stream);
-	if (oney) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, false, false, false>(a, grid, stream);
-	if (onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, false, false>(a, grid, stream);
-	return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, false, false>(a, grid, stream);
+	if (oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, true, false, false>(a, ft, grid, stream);
+	if (oney) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, false, false, false>(a, ft, grid, stream);
+	if (onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, false, false>(a, ft, grid, stream);
+	return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, false, false>(a, ft, grid, stream);
 }
 
 // out8: the destination holds 8-bit samples of a 10-bit path; oney / onec: the image holds the one-pattern form for luma /
 // chroma (vfgs_layout.h); wide: rows of more than kTileBlocks blocks (general form only); persist: a.persist_wgs luma workgroups
 // share the launch's luma tasks (10 bit, general-form luma, not wide), grid = persist_wgs + all chroma tasks; else grid =
 // workgroups per frame
-hipError_t launch_grain(const KernelArgs& a, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
+hipError_t launch_grain(const KernelArgs& a, const FrameTable* list, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
 {
 	if ((out8 && depth != 10) || wide != (a.nblk > kTileBlocks)) return hipErrorInvalidValue;
+	if ((a.listed != 0) != (list != nullptr) || (list && a.nframes > kListFrames)) return hipErrorInvalidValue;
+	static const FrameTable no_list{};
+	const FrameTable& ft = list ? *list : no_list;
 #define VFGS_CASE(D, X, Y)                                                                                                  \
 	if (depth == D && csubx == X && csuby == Y)                                                                             \
 	{                                                                                                                       \
-		if constexpr (D == 10) { if (out8) return launch_form<D, X, Y, true>(a, oney, onec, wide, persist, grid, stream); } \
-		return launch_form<D, X, Y, false>(a, oney, onec, wide, persist, grid, stream);                                     \
+		if constexpr (D == 10) { if (out8) return launch_form<D, X, Y, true>(a, ft, oney, onec, wide, persist, grid, stream); } \
+		return launch_form<D, X, Y, false>(a, ft, oney, onec, wide, persist, grid, stream);                                     \
 	}
 	VFGS_CASE(10, 2, 2) VFGS_CASE(10, 2, 1) VFGS_CASE(10, 1, 1) VFGS_CASE(10, 1, 2)
 	VFGS_CASE(8, 2, 2) VFGS_CASE(8, 2, 1) VFGS_CASE(8, 1, 1) VFGS_CASE(8, 1, 2)

@@ -137,6 +137,16 @@ struct PlaneDesc {
 	int rw_rpw, rw_splits, rw_lsplits;
 };
 
+// Frames of a batch that do NOT lie at a constant pitch (a decoder's pool of separately allocated frames, vfgs_hip_add_grain_frame_list_*):
+// their plane pointers travel in the kernel arguments themselves -- no device table to upload and keep alive, no copy on the
+// stream in front of the launch -- and a workgroup fetches its frame's pointers with one scalar load.  kListFrames frames per
+// launch (longer lists: several launches); 2 x 3 x 8 x kListFrames bytes of the 4 KB argument segment.
+constexpr int kListFrames = 32;
+struct FrameTable {
+	const uint8_t* src[3][kListFrames];   // [component][frame of the launch]: first line of the stripe
+	uint8_t* dst[3][kListFrames];
+};
+
 // One launch = nframes x (luma workgroups + 2 x chroma workgroups); workgroups are numbered in memory
 // order (frame, plane, block row group, split, column group) and are NOT persistent: the hardware
 // dispatcher hands them out as CUs free up.
@@ -154,6 +164,7 @@ struct KernelArgs {
 	int nblk;                 // 16-sample blocks per line = ceil(width/16), vfgs_hw.c:301
 	int nbrows;               // block rows the stripe touches
 	int nframes;
+	int listed;               // 1: the planes of frame f are FrameTable::src / dst [.][f] (src / dst above and the frame pitches are unused)
 	int lfronts;              // log2 of the frames of a batch that are swept at the same time (their workgroups are dealt out in turn)
 	int persist_wgs;          // PERSIST kernels: P luma workgroups share the launch's nframes x pd[0].wgs luma tasks (task t -> workgroup t % P) ...
 	int persist_step_f, persist_step_r;   // ... and P = persist_step_f * pd[0].wgs + persist_step_r: what a workgroup advances by

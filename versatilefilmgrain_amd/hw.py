@@ -103,6 +103,10 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_add_grain_copy_dev.argtypes = [vp, vp, vp, vp, vp, vp, u, u, u, u, u, u, u, C.c_uint64, C.c_uint64, vp]
     lib.vfgs_hip_add_grain_copy8_dev.argtypes = [vp, vp, vp, vp, vp, vp, u, u, u, u, u, u, u, u, u,
                                                  C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    fp = C.POINTER(FramePtrs)
+    lib.vfgs_hip_add_grain_frame_list_dev.argtypes = [fp, u, u, u, u, u, vp]
+    lib.vfgs_hip_add_grain_frame_list_copy_dev.argtypes = [fp, fp, u, u, u, u, u, vp]
+    lib.vfgs_hip_add_grain_frame_list_copy8_dev.argtypes = [fp, fp, u, u, u, u, u, u, u, vp]
     lib.vfgs_hip_get_seed_state.argtypes = [vp]
     lib.vfgs_hip_get_luts.argtypes = [i, vp, vp]
     lib.vfgs_hip_get_params.argtypes = [vp]
@@ -132,7 +136,12 @@ class LaunchInfo(C.Structure):
     _fields_ = [("depth", C.c_int), ("csubx", C.c_int), ("csuby", C.c_int), ("out8", C.c_int), ("one_y", C.c_int), ("one_c", C.c_int),
                 ("in_place", C.c_int), ("nframes", C.c_int), ("workgroups_per_frame", C.c_int), ("frames_per_front", C.c_int),
                 ("rows_per_wave", C.c_int * 2), ("positions_per_row", C.c_int * 2), ("parts_per_row", C.c_int), ("persistent_luma_workgroups", C.c_int),
-                ("waves_per_workgroup", C.c_int), ("lds_bytes_per_workgroup", C.c_int), ("launches", C.c_ulonglong), ("kernel", C.c_char * 96)]
+                ("waves_per_workgroup", C.c_int), ("lds_bytes_per_workgroup", C.c_int), ("launches", C.c_ulonglong), ("kernel", C.c_char * 96), ("listed", C.c_int)]
+
+
+class FramePtrs(C.Structure):
+    """include/vfgs_hip.h: vfgs_hip_frame_ptrs (device pointers to line 0 of one frame's planes)."""
+    _fields_ = [("Y", C.c_void_p), ("U", C.c_void_p), ("V", C.c_void_p)]
 
 
 EXPORTS = [
@@ -144,7 +153,8 @@ EXPORTS = [
     "vfgs_add_grain_stripe", "vfgs_hip_init", "vfgs_hip_shutdown", "vfgs_hip_reset_state",
     "vfgs_hip_add_grain_stripe_dev", "vfgs_hip_add_grain_frame_dev", "vfgs_hip_add_grain_frame_part_dev",
     "vfgs_hip_add_grain_frames_dev", "vfgs_hip_add_grain_frames_part_dev", "vfgs_hip_add_grain_copy_dev",
-    "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
+    "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_add_grain_frame_list_dev", "vfgs_hip_add_grain_frame_list_copy_dev",
+    "vfgs_hip_add_grain_frame_list_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
     "vfgs_hip_dev_build", "vfgs_hip_init_devices", "vfgs_hip_overlap_begin", "vfgs_hip_overlap_end", "vfgs_hip_get_stream_stats", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
     "vfgs_hip_add_grain_frames_host", "vfgs_hip_host_alloc", "vfgs_hip_host_free", "vfgs_hip_last_launch_info",
@@ -217,6 +227,31 @@ class VfgsHip:
         self._ck(self.lib.vfgs_hip_add_grain_copy8_dev(sY, sU, sV, dY, dU, dV, width, frame_height, part_y, part_height,
                                                        stride, cstride, dstride, dcstride, nframes, ypitch, cpitch,
                                                        dypitch, dcpitch, stream))
+
+    @staticmethod
+    def frame_list(frames):
+        """frames: sequence of (Y, U, V) device addresses -> ctypes array of vfgs_hip_frame_ptrs (build it once for a pool of
+        frames that is handed over again and again; the list calls take either form)."""
+        if isinstance(frames, C.Array):
+            return frames
+        arr = (FramePtrs * len(frames))()
+        for k, (y, u_, v) in enumerate(frames):
+            arr[k].Y, arr[k].U, arr[k].V = y, u_, v
+        return arr
+
+    def add_grain_frame_list_dev(self, frames, width, height, stride, cstride, stream=0):
+        """Frames anywhere in device memory, one launch per 32 of them (include/vfgs_hip.h)."""
+        self._ck(self.lib.vfgs_hip_add_grain_frame_list_dev(self.frame_list(frames), len(frames), width, height, stride, cstride, stream))
+
+    def add_grain_frame_list_copy_dev(self, src, dst, width, height, stride, cstride, stream=0):
+        assert len(src) == len(dst)
+        self._ck(self.lib.vfgs_hip_add_grain_frame_list_copy_dev(self.frame_list(src), self.frame_list(dst), len(src), width, height,
+                                                                 stride, cstride, stream))
+
+    def add_grain_frame_list_copy8_dev(self, src, dst, width, height, stride, cstride, dstride, dcstride, stream=0):
+        assert len(src) == len(dst)
+        self._ck(self.lib.vfgs_hip_add_grain_frame_list_copy8_dev(self.frame_list(src), self.frame_list(dst), len(src), width, height,
+                                                                  stride, cstride, dstride, dcstride, stream))
 
     def seed_state(self):
         out = (C.c_uint32 * 4)()
