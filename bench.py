@@ -62,25 +62,27 @@ def split_rows(nbr, n):
     return out
 
 
-def cpu_baseline(seconds=10.0):
-    """Reference (or oracle) hot path on ONE host core over whole 4320p frames."""
+def cpu_baseline(seconds=10.0, trace=TRACE, w=W, h=H, depth=DEPTH, sx=SUBX, sy=SUBY):
+    """Reference (or oracle) hot path on ONE host core over whole frames of the given workload (default: the headline's)."""
     import numpy as np
     import vfgs_testlib as T
 
-    rec = T.load_trace(TRACE)
+    rec = T.load_trace(trace)
     lib = T.oracle_lib()
-    frame, _ = T.lcg_frames(W, H, DEPTH, SUBX, SUBY, 1)
+    frame, _ = T.lcg_frames(w, h, depth, sx, sy, 1)
     f = frame[0]
+    note = None
     if T.have_reference():
-        kind, hw = "reference", T.ReferenceHW()
+        kind, hw, timed_lib = "reference", T.ReferenceHW(), str(T.REF_SO.relative_to(ROOT))
         T.replay(hw, rec)
         line = C.cast(hw.lib.vfgs_add_grain_line, C.c_void_p)
 
         def run(fr):
             lib.vfgs_oracle_drive_lines(line, C.c_void_p(fr.Y.ctypes.data), C.c_void_p(fr.U.ctypes.data),
-                                        C.c_void_p(fr.V.ctypes.data), fr.width, fr.height, fr.stride, fr.cstride, 2, SUBY)
+                                        C.c_void_p(fr.V.ctypes.data), fr.width, fr.height, fr.stride, fr.cstride, fr.Y.itemsize, sy)
     else:
-        kind, hw = "port", T.OracleHW()
+        kind, hw, timed_lib = "port", T.OracleHW(), str(T.ORACLE_SO.relative_to(ROOT))
+        note = "oracle/_ref/libvfgs_ref.so (the reference compiled in the build container) did not travel to this box: the repo's CPU restatement was timed instead"
         T.replay(hw, rec)
 
         def run(fr):
@@ -96,10 +98,13 @@ def cpu_baseline(seconds=10.0):
         spent += dt
         best = min(best, dt)
         n += 1
-    return {"value": round(W * H * n / spent / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": f"{n} frames 7680x4320 10-bit 4:2:0 fgs_sei, hot path only (line loop of vfgs_main.c:664-682), "
-                      f"mean {spent / n * 1e3:.1f} ms/frame, best {best * 1e3:.1f} ms/frame",
-            "host_cpus": os.cpu_count()}
+    out = {"value": round(w * h * n / spent / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": kind, "lib": timed_lib,
+           "sample": f"{n} frames {w}x{h} {depth}-bit {'4:4:4' if sx == 1 and sy == 1 else '4:2:0'} {trace.rsplit('_', 2)[0]}, hot path only "
+                     f"(line loop of vfgs_main.c:664-682), mean {spent / n * 1e3:.1f} ms/frame, best {best * 1e3:.1f} ms/frame",
+           "host_cpus": os.cpu_count()}
+    if note:
+        out["note"] = note
+    return out
 
 
 # everything that shapes the grain kernels' code object AND the launches the host makes of them: a profile (rocprof kernel
@@ -115,25 +120,51 @@ def kernel_sha():
     return h.hexdigest()[:16]
 
 
-# BASELINE.json configs[0..3] (configs[4] is the headline workload above): name, w, h, depth, (subx, suby), trace, frames per launch.
+# BASELINE.json configs[0..3] (configs[4] is the headline workload above): name, w, h, depth, (subx, suby), trace, variants.
 # Every configuration is reported at 8 frames per launch (the headline's batch) and at a larger batch (1080p: 400 MB, 2160p: 800 MB) -- a
-# launch pays ~5 us of fill, drain and kernel boundary, which is a quarter of a 100 MB launch.
+# launch pays ~5 us of fill, drain and kernel boundary, which is a quarter of a 100 MB launch.  A variant is
+# (frames per launch, how the frames lie in memory, content): "pitch" = one allocation, frames at a constant pitch
+# (vfgs_hip_add_grain_frames_dev); "list" = every frame three allocations of its own, in shuffled order with odd gaps, handed over as
+# a list of plane pointers (vfgs_hip_add_grain_frame_list_dev); content "uniform" = random over the full code range (the
+# worst case for LUT / pattern divergence), "ramp" = smooth diagonal ramp + -4..+4 noise (SURVEY 8d's secondary, natural-like content).
 CONFIGS = [
-    ("1920x1080 10-bit 4:2:0, cfg fgs_sei", 1920, 1080, 10, (2, 2), "fgs_sei_10_420", (8, 32)),
-    ("1920x1080 10-bit 4:2:0, cfg fgs_sei_ff_test1", 1920, 1080, 10, (2, 2), "fgs_sei_ff_test1_10_420", (8, 32)),
-    ("3840x2160 10-bit 4:2:0, cfg fgs_sei_ar_test1", 3840, 2160, 10, (2, 2), "fgs_sei_ar_test1_10_420", (8, 16)),
-    ("3840x2160 8-bit 4:4:4, cfg fgs_afgs1_test1", 3840, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", (8, 16)),
+    ("1920x1080 10-bit 4:2:0, cfg fgs_sei", 1920, 1080, 10, (2, 2), "fgs_sei_10_420", [(8, "pitch", "uniform"), (32, "pitch", "uniform"), (32, "list", "uniform")]),
+    ("1920x1080 10-bit 4:2:0, cfg fgs_sei_ff_test1", 1920, 1080, 10, (2, 2), "fgs_sei_ff_test1_10_420", [(8, "pitch", "uniform"), (32, "pitch", "uniform")]),
+    ("3840x2160 10-bit 4:2:0, cfg fgs_sei_ar_test1", 3840, 2160, 10, (2, 2), "fgs_sei_ar_test1_10_420", [(8, "pitch", "uniform"), (16, "pitch", "uniform")]),
+    ("3840x2160 8-bit 4:4:4, cfg fgs_afgs1_test1", 3840, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", [(8, "pitch", "uniform"), (16, "pitch", "uniform")]),
+    ("7680x4320 10-bit 4:2:0, cfg fgs_sei", W, H, DEPTH, (SUBX, SUBY), TRACE, [(8, "pitch", "ramp")]),
 ]
 
 
-def bench_configs(h, stream, steps_ms=60.0):
-    """BASELINE.json configs[0..3] on this GPU: device-resident frames, in place, plain stream, HIP events on the launching
-    stream; one post-timing launch of the timed shape per entry is compared with the oracle, frame by frame."""
+def fill_uniform(t, depth, g, chunk=1 << 26):
+    """uniform random samples into a flat device tensor, a bounded temporary at a time"""
+    import torch
+    for o in range(0, t.numel(), chunk):
+        n = min(chunk, t.numel() - o)
+        t[o:o + n] = torch.randint(0, 1 << depth, (n,), dtype=torch.int32, device=t.device, generator=g).to(t.dtype)
+
+
+def fill_ramp(t, depth, g, frame, rows, cols):
+    """one plane of frame `frame`: smooth diagonal ramp inside the legal range + -4..+4 noise (tools/bench_config.py --content ramp)"""
+    import torch
+    r = torch.arange(rows, device=t.device, dtype=torch.int32).view(rows, 1)
+    c = torch.arange(cols, device=t.device, dtype=torch.int32).view(1, cols)
+    lo, hi = (16 << (depth - 8)), (235 << (depth - 8))
+    base = lo + ((r * 3 + c * 2 + frame * 37) >> 3) % (hi - lo)
+    noise = torch.randint(-4, 5, (rows, cols), dtype=torch.int32, device=t.device, generator=g)
+    t.view(rows, cols).copy_((base + noise).clamp(0, (1 << depth) - 1).to(t.dtype))
+
+
+def bench_configs(h, stream, steps_ms=60.0, cpu_seconds=2.5):
+    """BASELINE.json configs[0..3] (+ the headline workload with natural-like content) on this GPU: device-resident frames, in place,
+    plain stream, HIP events on the launching stream; one post-timing launch of the timed shape per entry is compared with the
+    oracle, frame by frame; the reference's CPU path is timed beside every size (one core, a bounded sample)."""
+    import random
     import numpy as np
     import torch
     import vfgs_testlib as T
     out = []
-    for name, w, hh, depth, (sx, sy), trace, batches in CONFIGS:
+    for name, w, hh, depth, (sx, sy), trace, variants in CONFIGS:
         rec = T.load_trace(trace)
         dt = torch.int16 if depth > 8 else torch.uint8
         npdt = np.uint16 if depth > 8 else np.uint8
@@ -141,20 +172,48 @@ def bench_configs(h, stream, steps_ms=60.0):
         cw, ch = w // sx, hh // sy
         ny, nc = hh * w, ch * cw
         frame_bytes = sz * (ny + 2 * nc)
-        for batch in batches:
+        cpu = cpu_baseline(cpu_seconds, trace, w, hh, depth, sx, sy) if cpu_seconds > 0 else None
+        for batch, layout, content in variants:
             h.lib.vfgs_hip_reset_state()
             T.replay(h, rec)
             pool = max(3, int(1.0e9 // (frame_bytes * batch)) + 1)       # > 1 GB cycled through: nothing is served by the 256 MiB Infinity Cache
             g = torch.Generator(device="cuda").manual_seed(11)
-            sets = [torch.randint(0, 1 << depth, (batch * (ny + 2 * nc),), dtype=torch.int32, device="cuda", generator=g).to(dt) for _ in range(pool)]
+            rnd = random.Random(5)
+            keep = []                     # every allocation of this variant
+            sets = []                     # per buffer set: the planes of its frames, [(Y, U, V)] as flat tensors
+            for _ in range(pool):
+                if layout == "pitch":
+                    b = torch.empty(batch * (ny + 2 * nc), dtype=dt, device="cuda")
+                    keep.append(b)
+                    sets.append([(b[f * ny:(f + 1) * ny], b[batch * ny + f * nc:batch * ny + (f + 1) * nc],
+                                  b[batch * (ny + nc) + f * nc:batch * (ny + nc) + (f + 1) * nc]) for f in range(batch)])
+                else:
+                    planes = [None] * (3 * batch)
+                    order = list(range(3 * batch))
+                    rnd.shuffle(order)
+                    for k in order:
+                        planes[k] = torch.empty(ny if k % 3 == 0 else nc, dtype=dt, device="cuda")
+                        keep.append(torch.empty(rnd.randrange(1, 64) * 4096, dtype=torch.uint8, device="cuda"))      # a gap of odd size behind it
+                    keep.append(planes)
+                    sets.append([(planes[3 * f], planes[3 * f + 1], planes[3 * f + 2]) for f in range(batch)])
 
-            def ptrs(b):
-                p0 = b.data_ptr()
-                return p0, p0 + sz * batch * ny, p0 + sz * batch * (ny + nc)
+            def fill(frames, gen, kind):
+                for f, (y, u, v) in enumerate(frames):
+                    for t, rows, cols in ((y, hh, w), (u, ch, cw), (v, ch, cw)):
+                        if kind == "ramp":
+                            fill_ramp(t, depth, gen, f, rows, cols)
+                        else:
+                            fill_uniform(t, depth, gen)
+            for frames in sets:
+                fill(frames, g, content)
+            lists = [h.frame_list([(y.data_ptr(), u.data_ptr(), v.data_ptr()) for y, u, v in frames]) for frames in sets] if layout == "list" else None
 
             def step(i):
-                y, u, v = ptrs(sets[i % pool])
-                h.add_grain_frames_dev(y, u, v, w, hh, w, cw, batch, sz * ny, sz * nc, stream)
+                if lists:
+                    h.add_grain_frame_list_dev(lists[i % pool], w, hh, w, cw, stream)
+                else:
+                    y, u, v = sets[i % pool][0]
+                    h.add_grain_frames_dev(y.data_ptr(), u.data_ptr(), v.data_ptr(), w, hh, w, cw, batch, sz * ny, sz * nc, stream)
             t0, n = time.perf_counter(), 0
             while (time.perf_counter() - t0) * 1e3 < 40.0:          # untimed pre-roll
                 for _ in range(8):
@@ -171,39 +230,81 @@ def bench_configs(h, stream, steps_ms=60.0):
             torch.cuda.synchronize()
             launch_us = e0.elapsed_time(e1) / steps * 1e3
             info = h.last_launch_info()
-            # parity of the timed shape: fresh frames, reset seed state, every frame against the oracle
+            # parity of the timed shape: fresh frames of the same content, reset seed state, every frame against the oracle
             h.lib.vfgs_hip_reset_state()
             T.replay(h, rec)
             ora = T.OracleHW()
             T.replay(ora, rec)
-            gp = torch.Generator(device="cuda").manual_seed(4242)
-            sets[0].copy_(torch.randint(0, 1 << depth, (batch * (ny + 2 * nc),), dtype=torch.int32, device="cuda", generator=gp).to(dt))
-            src = sets[0].cpu().numpy().view(npdt)
+            fill(sets[0], torch.Generator(device="cuda").manual_seed(4242), content)
+            src = [tuple(t.cpu().numpy().view(npdt) for t in fr) for fr in sets[0]]
             step(0)
             torch.cuda.synchronize()
-            got = sets[0].cpu().numpy().view(npdt)
             bad = 0
-            for f in range(batch):
+            for f, (ys, us, vs) in enumerate(src):
                 fr = T.Frame(w, hh, depth, sx, sy, stride=w, cstride=cw)
-                yo, uo, vo = f * ny, batch * ny + f * nc, batch * (ny + nc) + f * nc
-                fr.Y[:hh] = src[yo:yo + ny].reshape(hh, w)           # (1080 lines: the allocation is padded to 1088, yuv.c:54-87)
-                fr.U[:ch] = src[uo:uo + nc].reshape(ch, cw)
-                fr.V[:ch] = src[vo:vo + nc].reshape(ch, cw)
+                fr.Y[:hh] = ys.reshape(hh, w)           # (1080 lines: the allocation is padded to 1088, yuv.c:54-87)
+                fr.U[:ch] = us.reshape(ch, cw)
+                fr.V[:ch] = vs.reshape(ch, cw)
                 ora.add_grain_frame(fr)
-                bad += not (np.array_equal(fr.Y[:hh].ravel(), got[yo:yo + ny]) and np.array_equal(fr.U[:ch].ravel(), got[uo:uo + nc])
-                            and np.array_equal(fr.V[:ch].ravel(), got[vo:vo + nc]))
+                gy, gu, gv = (t.cpu().numpy().view(npdt) for t in sets[0][f])
+                bad += not (np.array_equal(fr.Y[:hh].ravel(), gy) and np.array_equal(fr.U[:ch].ravel(), gu) and np.array_equal(fr.V[:ch].ravel(), gv))
             parity = bad == 0 and h.seed_state() == ora.seed_state()
             nbytes = 2 * frame_bytes * batch
             gbs = nbytes / (launch_us * 1e-6) / 1e9
-            out.append({"workload": name + ", seed 12345, uniform random samples", "frames_per_launch": batch, "steps": steps,
-                        "launch_us": round(launch_us, 2), "algorithmic_bytes_per_launch": nbytes, "achieved": round(gbs, 1),
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "mpixels_per_s": round(batch * w * hh / launch_us, 1),
-                        "kernel": info["kernel"] if info else None, "workgroups_per_frame": info["workgroups_per_frame"] if info else None,
-                        "persistent_luma_workgroups": info["persistent_luma_workgroups"] if info else None,
-                        "parity_checked": bool(parity)})
-            del sets
+            e = {"workload": name + f", seed 12345, {'uniform random samples' if content == 'uniform' else 'ramp + -4..+4 noise'}", "content": content,
+                 "frames_per_launch": batch, "frame_layout": "one allocation, constant frame pitch" if layout == "pitch" else "every plane its own allocation (frame list)",
+                 "steps": steps, "launch_us": round(launch_us, 2), "algorithmic_bytes_per_launch": nbytes, "achieved": round(gbs, 1),
+                 "frac": round(gbs / HBM_PEAK_GBS, 4), "mpixels_per_s": round(batch * w * hh / launch_us, 1),
+                 "kernel": info["kernel"] if info else None, "workgroups_per_frame": info["workgroups_per_frame"] if info else None,
+                 "persistent_luma_workgroups": info["persistent_luma_workgroups"] if info else None,
+                 "parity_checked": bool(parity)}
+            if cpu:
+                e["cpu_baseline"] = cpu
+            out.append(e)
+            del sets, keep, lists
             torch.cuda.empty_cache()
     return out
+
+
+def gpu_numa_cpus(index):
+    """CPUs of the NUMA node GPU `index` (HIP order) hangs off, from sysfs -- nothing here touches the GPU.  None if it cannot be told."""
+    try:
+        nodes = []
+        base = Path("/sys/class/kfd/kfd/topology/nodes")
+        for d in sorted(base.iterdir(), key=lambda p: int(p.name)):
+            try:      # (a container sees only the properties of the GPUs it was given: the others are not this process's devices)
+                props = dict(l.split() for l in (d / "properties").read_text().splitlines() if len(l.split()) == 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                nodes.append(props)
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            vis = os.environ.get(var)
+            if vis and all(x.strip().isdigit() for x in vis.split(",")):
+                nodes = [nodes[int(x)] for x in vis.split(",") if int(x) < len(nodes)]
+        p = nodes[index]
+        loc, dom = int(p["location_id"]), int(p.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+        cpus = set()
+        for part in (Path("/sys/bus/pci/devices") / bdf / "local_cpulist").read_text().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return bdf, cpus
+    except Exception:
+        return None
+
+
+def pin_to_gpu(index):
+    """Pin this process to the CPUs next to its GPU (before the first GPU call: the runtime's threads inherit the mask)."""
+    got = gpu_numa_cpus(index)
+    if not got:
+        return "not pinned (GPU -> NUMA node not found in sysfs)"
+    bdf, cpus = got
+    cpus &= os.sched_getaffinity(0)
+    if not cpus:
+        return f"not pinned (no allowed CPU next to {bdf})"
+    os.sched_setaffinity(0, cpus)
+    return f"{len(cpus)} CPUs local to {bdf} ({min(cpus)}-{max(cpus)})"
 
 
 def main():
@@ -253,9 +354,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     if args.rehearse_on_one_gpu:
         local = 0
+    affinity = pin_to_gpu(local) if world > 1 else "not pinned (one rank)"      # before anything touches the GPU
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local)
     if world > 1:
         # The data path has no collective (stripes are independent, DESIGN.md "multi-GPU"): the process group only
@@ -478,19 +580,24 @@ def main():
                        "pool_frames": pool * frames_per_launch, "msamples_per_s": round(mpix * 1.5, 1),
                        "preroll_ms": round(preroll_ms, 1), "preroll_launches": n_pre,
                        "sync_backend": "gloo (barrier + max only; no collective on the data path)" if world > 1 else "none",
-                       "n_ranks_seen": n_seen, "launch_us_per_rank": per_rank_us},
+                       "n_ranks_seen": n_seen, "launch_us_per_rank": per_rank_us, "cpu_affinity_rank0": affinity},
             "roofline": roof,
             "parity_checked": parity,
         }
         if world == 1 and not args.no_configs:
-            out["configs"] = bench_configs(h, stream)
+            # (a failure of this leg -- memory, a missing fixture -- must not cost the headline its line: it is recorded instead)
+            try:
+                out["configs"] = bench_configs(h, stream, cpu_seconds=0.0 if args.no_cpu else 2.5)
+            except Exception as ex:      # noqa: BLE001
+                out["configs"] = []
+                out["configs_error"] = f"{type(ex).__name__}: {ex}"
             if not all(c["parity_checked"] for c in out["configs"]):
                 parity = False
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(8.0)
         if parity is False:
             # a kernel that produced wrong bytes gets no benchmark line: the numbers are withheld and the exit code says so
-            bad_cfg = [c["workload"] for c in out.get("configs", []) if not c["parity_checked"]]
+            bad_cfg = [c["workload"] + f" x{c['frames_per_launch']} ({c['frame_layout']})" for c in out.get("configs", []) if not c["parity_checked"]]
             out = {"metric": out["metric"], "error": "parity failure: output differs from the oracle", "parity_checked": False,
                    "n_gpus": world, "failed_configs": bad_cfg}
         print(json.dumps(out), file=json_out, flush=True)

@@ -1048,18 +1048,26 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		break;
 	}
 
-	// seeds: every frame of the batch runs the full state machine; frame 0's part gives the offsets
+	// seeds: frames 0 and 1 run the state machine (vfgs_hw.c:291-298, 309-310; one step per block row); from the end of frame 0 on
+	// all four registers move by the same amount per frame -- a frame of nbr block rows rotates nbr - 1 times (not at line 0) and
+	// every rotation moves line_rnd, and line_rnd_up behind it, by one row of blocks: G = f (nbr - 1) + r, SURVEY 8a -- so the
+	// frames behind them are one addition each register, whatever the batch size
 	uint64_t first_cur = 0, first_up = 0, second_cur = 0, lo = ~0ull, hi = 0;
-	for (unsigned f = 0; f < nframes; f++)
+	for (unsigned f = 0; f < nframes && f < 2; f++)
 	{
 		StripePlan p = advance_seeds(s, frame_y, frame_h, nblk, part_y);
 		if (f == 0) { first_cur = p.cur0; first_up = p.up0; }
 		if (f == 1) second_cur = p.cur0;
-		if (f >= 2 && p.cur0 != first_cur + (second_cur - first_cur) * f)
-			return fail(10, "internal: batch seed positions are not equidistant");
 		lo = std::min(lo, std::min(p.cur0, p.up0));
 		hi = std::max(hi, p.cur0 + (uint64_t)nbr_stripe * nblk);
 		hi = std::max(hi, p.up0 + nblk);
+	}
+	if (nframes > 2)
+	{
+		if (frame_y != 0) return fail(10, "internal: a batch of stripes that do not begin at line 0");
+		const uint64_t step = second_cur - first_cur, more = (uint64_t)(nframes - 2) * step;
+		s.rnd += more; s.rnd_up += more; s.line_rnd += more; s.line_rnd_up += more;
+		hi = std::max(hi, second_cur + more + (uint64_t)nbr_stripe * nblk);
 	}
 	// Images are uploaded on the stream of the call that needs them first; a call on ANOTHER stream waits (once) for that
 	// upload, and a slot is only overwritten after all its readers (SlotGuard)
