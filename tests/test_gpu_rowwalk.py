@@ -15,7 +15,7 @@ from gpu_util import DevFrame, stream_ptr
 pytestmark = pytest.mark.gpu
 
 FORMATS = ["fgs_sei_10_420", "fgs_afgs1_test1_8_420", "fgs_sei_8_420", "fgs_afgs1_test1_8_444", "fgs_sei_10_422", "fgs_sei_ff_test6_8_422", "fgs_sei_10_444",
-           "fgs_sei_ff_test6_10_440"]
+           "fgs_sei_ff_test6_10_440", "fgs_sei_ff_test6_8_444"]
 # 10-bit luma: a unit = 8 samples, a position = 512 samples, a group = 2048; 8-bit: twice that
 WIDTHS = [136, 504, 512, 520, 1016, 1024, 1032, 2040, 2048, 2056, 2064, 4096, 4104]
 HEIGHTS = [16, 17, 33, 64, 70]
@@ -103,15 +103,20 @@ def test_widest_row_of_the_parameter_table_and_one_block_more(hip, width, parts)
 
 
 WIDE_FORMATS = ["fgs_sei_10_420", "fgs_afgs1_test1_8_420", "fgs_sei_8_420", "fgs_afgs1_test1_8_444", "fgs_sei_10_422", "fgs_sei_10_444",
-                "fgs_sei_ff_test6_10_440", "fgs_sei_ar_test1_10_420"]
+                "fgs_sei_ff_test6_10_440", "fgs_sei_ar_test1_10_420", "fgs_afgs1_test1_10_444", "fgs_sei_ff_test6_10_444", "fgs_afgs1_test3_10_422"]
+# the form of the table image a wide picture gets (luma, chroma): at 4:2:0 and 4:4:4 one-pattern chroma keeps its form, and luma under
+# it; every other case falls back to the general form (vfgs_host.cpp image_form, vfgs_kernel.hip launch_form)
+WIDE_FORM = {"fgs_sei_10_420": (0, 1), "fgs_afgs1_test1_8_420": (1, 1), "fgs_sei_8_420": (0, 1), "fgs_afgs1_test1_8_444": (1, 1), "fgs_sei_10_422": (0, 0),
+             "fgs_sei_10_444": (0, 1), "fgs_sei_ff_test6_10_440": (0, 0), "fgs_sei_ar_test1_10_420": (1, 1), "fgs_afgs1_test1_10_444": (1, 1),
+             "fgs_sei_ff_test6_10_444": (0, 0), "fgs_afgs1_test3_10_422": (0, 0)}
 
 
 @pytest.mark.parametrize("name", WIDE_FORMATS)
 @pytest.mark.parametrize("width", [8208, 12288, 16384, 16400])
 def test_rows_walked_in_parts(hip, name, width):
     """Rows of 513, 768, 1024 and 1025 blocks (two or three passes over the parameter table): every chroma format, both depths,
-    one-pattern configurations (which run the general form here), a stripe that ends inside a block row, two frames per launch
-    through the stripe + frame entry points.  The table is refilled between two barriers while the ring of register sets runs on."""
+    one-pattern configurations (which keep their form at 4:2:0 and 4:4:4), a stripe that ends inside a block row, two frames per
+    launch through the stripe + frame entry points.  The table is refilled between two barriers while the ring of register sets runs on."""
     ora, (depth, sx, sy) = program(hip, name)
     for height in (16, 40):
         f = garbage_frame(width, height, depth, sx, sy, width + height)
@@ -122,7 +127,8 @@ def test_rows_walked_in_parts(hip, name, width):
         assert d.download().equal_all(want), (name, width, height)
         assert hip.seed_state() == ora.seed_state()
     info = hip.last_launch_info()
-    assert info["parts_per_row"] == (width + 15) // 16 // 512 + ((width + 15) // 16 % 512 > 0) and info["one_y"] == 0 and info["one_c"] == 0
+    assert info["parts_per_row"] == (width + 15) // 16 // 512 + ((width + 15) // 16 % 512 > 0)
+    assert (info["one_y"], info["one_c"]) == WIDE_FORM[name], info
     assert info["rows_per_wave"] == [1, 1]
 
 
@@ -140,9 +146,10 @@ def test_widest_picture(hip):
 
 
 def test_wide_and_narrow_pictures_alternate_with_one_pattern_configuration(hip):
-    """A one-pattern configuration: pictures of up to 8192 samples use the one-pattern table image, wider ones the general form --
-    the image is rebuilt when the width class changes, in both directions, without a setter call in between."""
-    ora, (depth, sx, sy) = program(hip, "fgs_afgs1_test1_8_420")
+    """A one-pattern configuration at 4:2:2: pictures of up to 8192 samples use the one-pattern table image, wider ones the general
+    form (the one-pattern kernels of rows walked in parts exist at 4:2:0 and 4:4:4) -- the image is rebuilt when the width class
+    changes, in both directions, without a setter call in between."""
+    ora, (depth, sx, sy) = program(hip, "fgs_afgs1_test3_10_422")
     for i, width in enumerate([1024, 8208, 2048, 16384, 8192]):
         f = garbage_frame(width, 32, depth, sx, sy, 50 + i)
         want = f.copy()

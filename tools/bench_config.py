@@ -31,6 +31,13 @@ CONFIGS = [  # BASELINE.json configs[i]: name, w, h, depth, (subx, suby), trace,
     ("7680x4320 10-bit 4:2:0 fgs_afgs1_test1", 7680, 4320, 10, (2, 2), "fgs_afgs1_test1_10_420", "grain_rw_kernel<10,2,2,true,true>"),
     # the mainstream SEI case: several luma patterns (general form) at 2160p
     ("3840x2160 10-bit 4:2:0 fgs_sei", 3840, 2160, 10, (2, 2), "fgs_sei_10_420", "grain_rw_kernel<10,2,2,...>"),
+    # 11, 12: 4:4:4 with several chroma patterns (general-form chroma: the image that used to hold a CU to three workgroups)
+    ("3840x2160 10-bit 4:4:4 fgs_sei_ff_test6", 3840, 2160, 10, (1, 1), "fgs_sei_ff_test6_10_444", "grain_rw_kernel<10,1,1,...>"),
+    ("3840x2160 8-bit 4:4:4 fgs_sei_ff_test6", 3840, 2160, 8, (1, 1), "fgs_sei_ff_test6_8_444", "grain_rw_kernel<8,1,1,...>"),
+    # 13 .. 15: rows of 1024 blocks (walked in two parts): one-pattern forms, one-pattern chroma under general-form luma
+    ("16384x2160 10-bit 4:2:0 fgs_afgs1_test1", 16384, 2160, 10, (2, 2), "fgs_afgs1_test1_10_420", "grain_rw_kernel<10,2,2,false,true,true,true,false>"),
+    ("16384x2160 8-bit 4:4:4 fgs_afgs1_test1", 16384, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", "grain_rw_kernel<8,1,1,false,true,true,true,false>"),
+    ("16384x2160 10-bit 4:2:0 fgs_sei", 16384, 2160, 10, (2, 2), "fgs_sei_10_420", "grain_rw_kernel<10,2,2,false,false,true,true,false>"),
 ]
 
 

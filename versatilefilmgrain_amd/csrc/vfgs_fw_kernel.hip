@@ -378,7 +378,8 @@ __global__ __launch_bounds__(256) void fw_patch_tables(const PatchArgs p)
 		else
 			for (int k = 0; k < kSlots; k++)
 				if (p.mask_chroma >> k & 1)
-					p.img[L.c_off[0] + L.c_bank + r * L.c_rs + x * kSlots + k] = (uint8_t)p.bank[(size_t)(kSlots + k) * 4096 + r * 64 + x];
+					for (int c = 0; c < 2; c++)      // (the general form holds the chroma bank once per component's sub-image)
+						p.img[L.c_off[c] + L.c_bank + r * L.c_rs + x * kSlots + k] = (uint8_t)p.bank[(size_t)(kSlots + k) * 4096 + r * 64 + x];
 	}
 }
 

@@ -780,7 +780,7 @@ void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool
 			else
 				for (int k = 0; k < vfgs::kSlots; k++) yb[r * L.y_rs + x * vfgs::kSlots + k] = (uint8_t)s.bank[0][k][r][x];
 		}
-	for (int c = 0; c < (one_c ? 2 : 1); c++)
+	for (int c = 0; c < 2; c++)       // (one sub-image per chroma component in both forms, vfgs_layout.h)
 	{
 		uint8_t* cb = img + L.c_off[c] + L.c_bank;
 		for (int r = 0; r < L.ch; r++)
@@ -835,11 +835,13 @@ int check_luts(State& s)
 	return 0;
 }
 
-// Which form of the table image (vfgs_layout.h) the current state gets.  want_general: the caller needs the general
-// (slot-interleaved) form even where one pattern would do (pictures wider than 8192 samples: their kernels exist in the general
-// form only).  The pattern LUTs must have been digested.
-void image_form(const State& s, bool want_general, bool* one_y, bool* one_c)
+// Which form of the table image (vfgs_layout.h) the current state gets.  wide: the picture is wider than 8192 samples (rows walked
+// in parts); those kernels exist for the combinations that matter there -- everything general, one-pattern chroma under general
+// or one-pattern luma, at 4:2:0 and 4:4:4 (vfgs_kernel.hip launch_form) -- and every other case gets the general form even where
+// one pattern would do.  The pattern LUTs must have been digested.
+void image_form(const State& s, bool wide, bool* one_y, bool* one_c)
 {
+	bool want_general = false;
 #ifdef VFGS_NO_ONE_PATTERN      // tools/gpu_variants.sh: always the general form
 	want_general = true;
 #endif
@@ -855,6 +857,7 @@ void image_form(const State& s, bool want_general, bool* one_y, bool* one_c)
 	};
 	*one_y = !want_general && slot[0] >= 0 && negatable(0, slot[0]);
 	*one_c = !want_general && slot[1] >= 0 && slot[2] >= 0 && negatable(1, slot[1]) && negatable(1, slot[2]);
+	if (wide && !(s.csubx == s.csuby && *one_c)) *one_y = *one_c = false;
 }
 
 // the form is a function of the programmed state and of want_general: an image that is not dirty keeps its own
@@ -1008,7 +1011,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	int rw_shrink = 0;                      // halvings of the rows per wave (small launches)
 	bool form_one_y = false, form_one_c = false;   // the form the table image will have (upload_tables below)
 	digest_pluts(s);
-	const bool wide = nparts > 1;           // the kernels of rows walked in parts exist in the general form only
+	const bool wide = nparts > 1;           // rows walked in parts: not every form of the table image has such a kernel (image_form)
 	if (image_is_current(s, wide)) form_one_y = s.img_one_y;
 	else if (s.plut_bad_c < 0) image_form(s, wide, &form_one_y, &form_one_c);
 	(void)form_one_c;

@@ -436,7 +436,7 @@ __device__ __forceinline__ void store_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v
 //   * row bases and position offsets live in the buffer descriptor (base, num_records = bytes of the row left), so the
 //     hardware range check covers every access of every lane: lanes behind the row's end load 0 and store nothing
 //     (8-bit 4:2:x rows of an odd number of blocks end in HALF a unit: the check works per dword);
-//   * rows of more than kTileBlocks blocks (WIDE kernels, general form of the table image only): the table holds one PART of
+//   * rows of more than kTileBlocks blocks (WIDE kernels): the table holds one PART of
 //     the row (kTileBlocks blocks) at a time; all waves walk part 0 of their row, the workgroup refills the table for part 1
 //     between two barriers, and so on -- the ring of register sets simply runs on (the host gives such workgroups one row per wave);
 //   * OUT8 (10-bit source, 8-bit destination, yuv.c:216-258): out8 = (v + 2) >> 2 is applied to a lane's results, which
@@ -853,12 +853,12 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 // allocation granule above the 96 of five waves: asking for five costs one register spilled in the prologue and reloaded
 // once per row (not in the group loop) and is worth 3 % (profiles/r03_ab22_lds_probes_and_occupancy.log); the general-form
 // kernels are held at four by their LDS image, the others by spills.
-template <int DEPTH, bool ONEY, bool ONEC>
-constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && VFGS_WG_PER_CU == 4) ? 5 : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
+template <int DEPTH, bool ONEY, bool ONEC, bool WIDE>
+constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && !WIDE && VFGS_WG_PER_CU == 4) ? 5 : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
 
 // in place or out of place; workgroups numbered frame -> plane -> block row -> part of the block row
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>
-__global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC>())) void grain_rw_kernel(const KernelArgs a, const FrameTable ft)
+__global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC, WIDE>())) void grain_rw_kernel(const KernelArgs a, const FrameTable ft)
 {
 	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes + kParamBytes];
@@ -923,7 +923,18 @@ static hipError_t launch_t(const KernelArgs& a, const FrameTable& ft, int grid, 
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8>
 static hipError_t launch_form(const KernelArgs& a, const FrameTable& ft, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
 {
-	if (wide) return (oney || onec || persist) ? hipErrorInvalidValue : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, true, false>(a, ft, grid, stream);
+	if (wide)
+	{
+		// rows walked in parts: the general form for every format; at 4:2:0 and 4:4:4 also one-pattern chroma under either luma form
+		// (the default SEI model: eight luma patterns, one chroma pattern; AFGS1 and the single-pattern SEI models: one each)
+		if (persist) return hipErrorInvalidValue;
+		if constexpr (CSUBX == CSUBY)
+		{
+			if (oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, true, true, true, false>(a, ft, grid, stream);
+			if (!oney && onec) return launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, true, true, false>(a, ft, grid, stream);
+		}
+		return (oney || onec) ? hipErrorInvalidValue : launch_t<DEPTH, CSUBX, CSUBY, OUT8, false, false, true, false>(a, ft, grid, stream);
+	}
 	if constexpr (DEPTH == 10)     // (the host asks for persistence at 10 bit only)
 	{
 		if (persist)
@@ -941,7 +952,7 @@ static hipError_t launch_form(const KernelArgs& a, const FrameTable& ft, bool on
 }
 
 // out8: the destination holds 8-bit samples of a 10-bit path; oney / onec: the image holds the one-pattern form for luma /
-// chroma (vfgs_layout.h); wide: rows of more than kTileBlocks blocks (general form only); persist: a.persist_wgs luma workgroups
+// chroma (vfgs_layout.h); wide: rows of more than kTileBlocks blocks (launch_form: which forms exist); persist: a.persist_wgs luma workgroups
 // share the launch's luma tasks (10 bit, general-form luma, not wide), grid = persist_wgs + all chroma tasks; else grid =
 // workgroups per frame
 hipError_t launch_grain(const KernelArgs& a, const FrameTable* list, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)

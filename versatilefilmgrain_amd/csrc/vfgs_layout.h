@@ -57,7 +57,10 @@ constexpr int kParamBytes = 2 * kParamTableBytes;
 // component -- and a workgroup (which works on ONE plane) copies the sub-image of its plane to LDS offset 0.
 //
 //   luma image  : [LUT Y : 2 x 256 dwords] [luma bank]          (one-pattern form: 1 x 256 dwords, the +scale table, then the bank and its negated copy)
-//   chroma image: [LUT Cb: 2 x 256 dwords] [LUT Cr: 2 x 256 dwords] [chroma bank]                 (general form)
+//   Cb image    : [LUT Cb: 2 x 256 dwords] [chroma bank]        (general form: the chroma bank is stored twice in the device image, so that a
+//   Cr image    : [LUT Cr: 2 x 256 dwords] [chroma bank]         workgroup -- which serves ONE component -- stages one LUT pair, not two: with both,
+//                                                                 the 4:4:4 chroma image was 2 KB larger than the luma image and a CU held three
+//                                                                 workgroups where the kernels are built for four)
 //             or: [LUT Cb] [bank of Cb's pattern]   and   [LUT Cr] [bank of Cr's pattern]          (one-pattern form)
 //
 // GENERAL form of a bank ("slot-interleaved"): for every (row, column) position the eight slots' int8 values sit in 8
@@ -105,17 +108,17 @@ constexpr ImageLayout image_layout(int csubx, int csuby, bool one_y, bool one_c)
 	L.c_rs = one_c ? L.cw + 16 : L.cw * kSlots + 16;
 	// (the one-pattern form never reads the -scale table: its sign is a choice of bank; only the +scale half is stored)
 	L.y_bank = one_y ? L.lut_bytes / 2 : L.lut_bytes;
-	L.c_bank = one_c ? L.lut_bytes / 2 : 2 * L.lut_bytes;
+	L.c_bank = one_c ? L.lut_bytes / 2 : L.lut_bytes;
 	L.y_neg = one_y ? 64 * L.y_rs : 0;
 	L.c_neg = one_c ? L.ch * L.c_rs : 0;
 	L.y_bytes = L.y_bank + 64 * L.y_rs + L.y_neg;
 	L.c_bytes = L.c_bank + L.ch * L.c_rs + L.c_neg;
 	L.y_off = 0;
 	L.c_off[0] = L.y_bytes;
-	L.c_off[1] = one_c ? L.y_bytes + L.c_bytes : L.y_bytes;
+	L.c_off[1] = L.y_bytes + L.c_bytes;
 	L.c_lut[0] = 0;
-	L.c_lut[1] = one_c ? 0 : L.lut_bytes;
-	L.bytes = L.y_bytes + (one_c ? 2 : 1) * L.c_bytes;
+	L.c_lut[1] = 0;
+	L.bytes = L.y_bytes + 2 * L.c_bytes;
 	L.lds_bytes = L.y_bytes > L.c_bytes ? L.y_bytes : L.c_bytes;
 	return L;
 }
