@@ -236,7 +236,10 @@ void vfgs_hip_host_free(void* p);
 int vfgs_hip_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* name, int name_len);
 
 /* What the most recent grain launch of this process (primary device) actually dispatched -- so that a benchmark labels
- * its numbers with the kernel that ran instead of the kernel it expects.  `kernel` is the instantiation's name as the
+ * its numbers with the kernel that ran instead of the kernel it expects.  EVERY grain launch is recorded and counted in
+ * `launches`, also those the host-memory entry points make on the library's own staging buffers (`internal` = 1: a line of
+ * vfgs_add_grain_line, the stripes it computes ahead -- including ones that are dropped later --, vfgs_add_grain_stripe,
+ * vfgs_hip_add_grain_frames_host): after a walk through the line call the record describes such a stripe launch.  `kernel` is the instantiation's name as the
  * profiler prints it (e.g. "grain_rw_kernel<10,2,2,false,false,true,false,false>": depth, chroma subsampling
  * x / y, 8-bit destination of a 10-bit path, luma one-pattern form, chroma one-pattern form, rows walked in parts,
  * persistent luma workgroups).  Returns 0, or -1 when nothing has been launched yet. */
@@ -257,6 +260,7 @@ typedef struct vfgs_hip_launch_info {
 	unsigned long long launches;      /* grain launches of this process so far */
 	char kernel[96];
 	int listed;                       /* 1: the frames' plane pointers came as a list (vfgs_hip_add_grain_frame_list_*) */
+	int internal;                     /* 1: launched by a host-memory entry point on the library's staging buffers, not on a caller's device planes */
 } vfgs_hip_launch_info;
 int vfgs_hip_last_launch_info(vfgs_hip_launch_info* out);
 

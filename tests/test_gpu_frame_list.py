@@ -71,7 +71,7 @@ def test_scattered_frames_equal_one_call_per_frame(hip, name):
     frames = [garbage_frame(1032, 90, depth, sx, sy, 10 + i) for i in range(7)]
     run_list(hip, ora, frames)
     info = hip.last_launch_info()
-    assert info["listed"] == 1 and info["nframes"] == 7 and info["in_place"] == 1, info
+    assert info["listed"] == 1 and info["nframes"] == 7 and info["in_place"] == 1 and info["internal"] == 0, info
 
 
 def test_lists_mixed_with_the_other_entry_points(hip):

@@ -646,6 +646,7 @@ def test_line_api_frame_height_promised_through_the_environment(hip, monkeypatch
     assert a.equal_all(b)
     n1 = hip.last_launch_info()["launches"]
     assert n1 - n0 >= h            # no promise: a launch per line
+    assert hip.last_launch_info()["internal"] == 1      # ... on the library's staging buffers, and the record says so
     monkeypatch.setenv("VFGS_HIP_FRAME_HEIGHT", str(h))
     for f in frames[1:]:           # fresh buffers: never walked before
         a, b = f.copy(), f.copy()

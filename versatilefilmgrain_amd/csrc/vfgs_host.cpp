@@ -600,6 +600,13 @@ std::mutex g_mu;
 
 vfgs_hip_launch_info g_last_launch{};      // what the primary state's most recent grain launch dispatched
 bool g_last_launch_valid = false;
+// set while a host-memory entry point (the line call and its look-ahead stripes, vfgs_add_grain_stripe, vfgs_hip_add_grain_frames_host)
+// launches on the library's own staging buffers: vfgs_hip_last_launch_info().internal
+bool g_internal_launch = false;
+struct InternalLaunch {
+	InternalLaunch() { g_internal_launch = true; }
+	~InternalLaunch() { g_internal_launch = false; }
+};
 
 int ensure_init(int device)
 {
@@ -1131,6 +1138,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		li.out8 = dg.out8; li.one_y = s.img_one_y; li.one_c = s.img_one_c;
 		li.in_place = (sY == dY && sU == dU && sV == dV);
 		li.listed = a.listed;
+		li.internal = g_internal_launch ? 1 : 0;
 		li.nframes = (int)nframes;
 		li.workgroups_per_frame = (int)per_frame;
 		li.frames_per_front = 1 << a.lfronts;
@@ -1212,9 +1220,12 @@ int run_host(void* Y, void* U, void* V, unsigned y, unsigned width, unsigned hei
 		else
 			HIP_TRY(hipMemcpy2DAsync(s.stage[i], dpitch[i], host[i], spitch[i], rowlen[i], rows[i], hipMemcpyHostToDevice, s.own_stream));
 	}
-	if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], s.stage[0], s.stage[1], s.stage[2], width, y, height, py, ph,
-	                       dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, s.own_stream))
-		return e;
+	{
+		InternalLaunch mark;
+		if (int e = run_device(s.stage[0], s.stage[1], s.stage[2], s.stage[0], s.stage[1], s.stage[2], width, y, height, py, ph,
+		                       dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, s.own_stream))
+			return e;
+	}
 	for (int i = 0; i < 3; i++)
 	{
 		if (via_bounce) HIP_TRY(hipMemcpyAsync(s.bounce[i], s.stage[i], (size_t)dpitch[i] * rows[i], hipMemcpyDeviceToHost, s.own_stream));
@@ -1309,8 +1320,11 @@ int run_host_frames(void* const* Y, void* const* U, void* const* V, unsigned nfr
 		}
 		if (!ok) break;
 		if (!hip(hipEventRecord(P.up_done[k], P.up), "hipEventRecord") || !hip(hipStreamWaitEvent(P.run, P.up_done[k], 0), "hipStreamWaitEvent")) break;
-		rc = run_device(P.dev[k][0], P.dev[k][1], P.dev[k][2], P.dev[k][0], P.dev[k][1], P.dev[k][2], width, 0, height, py, ph,
-		                dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, P.run);
+		{
+			InternalLaunch mark;
+			rc = run_device(P.dev[k][0], P.dev[k][1], P.dev[k][2], P.dev[k][0], P.dev[k][1], P.dev[k][2], width, 0, height, py, ph,
+			                dpitch[0] / sz, dpitch[1] / sz, 1, 0, 0, P.run);
+		}
 		if (rc) break;
 		if (!hip(hipEventRecord(P.run_done[k], P.run), "hipEventRecord") || !hip(hipStreamWaitEvent(P.down, P.run_done[k], 0), "hipStreamWaitEvent")) break;
 		for (int i = 0; i < 3 && ok; i++)
@@ -1469,8 +1483,12 @@ int lookahead_issue_impl(State& s, int k, unsigned y0, unsigned n)
 	// the kernel runs from the registers behind the previous stripe; the caller's registers only move when it hands lines over
 	const uint64_t keep[4] = {s.rnd, s.rnd_up, s.line_rnd, s.line_rnd_up};
 	s.rnd = la.spec[0]; s.rnd_up = la.spec[1]; s.line_rnd = la.spec[2]; s.line_rnd_up = la.spec[3];
-	const int e = run_device(sl.dev[0], sl.dev[1], sl.dev[2], sl.dev[0], sl.dev[1], sl.dev[2], la.width, y0, n, y0, n,
-	                         la.dpitch[0] / sz, la.dpitch[1] / sz, 1, 0, 0, la.run);
+	int e;
+	{
+		InternalLaunch mark;
+		e = run_device(sl.dev[0], sl.dev[1], sl.dev[2], sl.dev[0], sl.dev[1], sl.dev[2], la.width, y0, n, y0, n,
+		               la.dpitch[0] / sz, la.dpitch[1] / sz, 1, 0, 0, la.run);
+	}
 	la.spec[0] = s.rnd; la.spec[1] = s.rnd_up; la.spec[2] = s.line_rnd; la.spec[3] = s.line_rnd_up;
 	s.rnd = keep[0]; s.rnd_up = keep[1]; s.line_rnd = keep[2]; s.line_rnd_up = keep[3];
 	if (e) return e;
@@ -1582,7 +1600,9 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 			{
 				la.slot[la.head].used = false;
 				la.head = nh;
-				if (int e = lookahead_extend(s)) return e;
+				// (a failure to queue stripes FURTHER ahead is about later lines: this line is then computed alone below -- a miss --
+				// so that the caller, who gets no error code from the void drop-in call, still receives it and the registers stay in step)
+				if (lookahead_extend(s)) hit = false;
 			}
 		}
 		if (hit)
@@ -1590,9 +1610,13 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 			State::LineAhead::Slot& sl = la.slot[la.head];
 			if (!sl.waited)
 			{
-				HIP_TRY(hipEventSynchronize(sl.done));
-				sl.waited = true;
+				if (hipEventSynchronize(sl.done) != hipSuccess) { (void)hipGetLastError(); hit = false; }
+				else sl.waited = true;
 			}
+		}
+		if (hit)
+		{
+			State::LineAhead::Slot& sl = la.slot[la.head];
 			const size_t k = y - sl.y0, crow = (size_t)(y / s.csuby - sl.crow0);
 			const bool chroma = (y % s.csuby) == 0;
 			hit = !memcmp(cY, sl.in[0] + k * la.dpitch[0], la.rowlen[0]) &&
@@ -1637,6 +1661,8 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 		{
 			if (la.declared && !(cY == la.bY && cU == la.bU && cV == la.bV && width == la.pwidth))
 				la.declared = false, la.ypitch = la.cpitch = 0, la.frame_h = 0;      // not the declared frame
+			else if (!la.declared && !(cY == la.bY && cU == la.bU && cV == la.bV))
+				la.ypitch = la.cpitch = 0;      // another buffer: the pitches of the previous walk prove nothing about this one (they are learned again from its first lines)
 			la.bY = cY; la.bU = cU; la.bV = cV;
 			la.from_zero = true;
 		}

@@ -136,7 +136,7 @@ class LaunchInfo(C.Structure):
     _fields_ = [("depth", C.c_int), ("csubx", C.c_int), ("csuby", C.c_int), ("out8", C.c_int), ("one_y", C.c_int), ("one_c", C.c_int),
                 ("in_place", C.c_int), ("nframes", C.c_int), ("workgroups_per_frame", C.c_int), ("frames_per_front", C.c_int),
                 ("rows_per_wave", C.c_int * 2), ("positions_per_row", C.c_int * 2), ("parts_per_row", C.c_int), ("persistent_luma_workgroups", C.c_int),
-                ("waves_per_workgroup", C.c_int), ("lds_bytes_per_workgroup", C.c_int), ("launches", C.c_ulonglong), ("kernel", C.c_char * 96), ("listed", C.c_int)]
+                ("waves_per_workgroup", C.c_int), ("lds_bytes_per_workgroup", C.c_int), ("launches", C.c_ulonglong), ("kernel", C.c_char * 96), ("listed", C.c_int), ("internal", C.c_int)]
 
 
 class FramePtrs(C.Structure):
