@@ -7,6 +7,7 @@ usage: tools/dev/make_ablation_src.py <outdir> [patch:<file>] [nolut] [nopat] [n
   nolut    8-bit LUT "gather" takes the address itself (address arithmetic stays, no LDS read)
   nopat    one-pattern forms: pattern values from registers instead of the LDS read
   nograin  no grain_unit at all: the rows are only walked (loads, lane rotation, stores)
+  nograin_luma / nograin_chroma  the same for one plane type only: which planes' arithmetic costs what
   noprologue  (with nograin) no table image, no block parameters, no barriers: the bare walk
   pad:N    every table image N bytes larger (staged and never read): what the size of the image costs
   git:REV  take the sources from that revision instead of the working tree
@@ -54,6 +55,10 @@ if "nopat" in opts and w16:
 if "nograin" in opts:
     rep("if (NU * g + u < tsegs)\n", "if (false)\n")
     rep("if (valid)\n\t\t\t\t{\n\t\t\t\t\tconst int j = base", "if (false)\n\t\t\t\t{\n\t\t\t\t\tconst int j = base")
+for which, cond in (("nograin_luma", "comp != 0"), ("nograin_chroma", "comp == 0")):
+    if which in opts:
+        rep("if (NU * g + u < tsegs)\n", "if (%s && NU * g + u < tsegs)\n" % cond)
+        rep("if (valid)\n\t\t\t\t{\n\t\t\t\t\tconst int j = base", "if (%s && valid)\n\t\t\t\t{\n\t\t\t\t\tconst int j = base" % cond)
 if "noprologue" in opts:
     assert s.count("if (!PERSIST || first_task)\n") == 2
     s = s.replace("if (!PERSIST || first_task)\n", "if (false)\n")
