@@ -445,7 +445,7 @@ struct State {
 	int cu_count = 0;
 	bool tables_dirty = true;
 	bool img_one_y = false, img_one_c = false;   // form of the current table image (vfgs_layout.h: one-pattern form)
-	bool img_want_general = false;               // ... and what its caller asked for (image_form's second argument)
+	bool img_wide = false;                       // ... and the width class it was built for (image_form's second argument)
 	DevRing tables_ring;
 	// staging for the host-pointer entry points
 	void* stage[3] = {nullptr, nullptr, nullptr};
@@ -867,22 +867,22 @@ void image_form(const State& s, bool wide, bool* one_y, bool* one_c)
 	if (wide && !(s.csubx == s.csuby && *one_c)) *one_y = *one_c = false;
 }
 
-// the form is a function of the programmed state and of want_general: an image that is not dirty keeps its own
-bool image_is_current(const State& s, bool want_general)
+// the form is a function of the programmed state and of the width class: an image that is not dirty keeps its own
+bool image_is_current(const State& s, bool wide)
 {
-	return !s.tables_dirty && s.tables_ring.current() && s.img_want_general == want_general;
+	return !s.tables_dirty && s.tables_ring.current() && s.img_wide == wide;
 }
 
-int upload_tables(State& s, hipStream_t stream, bool want_general)
+int upload_tables(State& s, hipStream_t stream, bool wide)
 {
 	if (int e = check_luts(s)) return e;
-	if (image_is_current(s, want_general)) return 0;     // (the steady state: nothing is looked at per call)
+	if (image_is_current(s, wide)) return 0;     // (the steady state: nothing is looked at per call)
 	const int slot[3] = {s.plut_slot[0], s.plut_slot[1], s.plut_slot[2]};     // (check_luts has just digested them)
 	bool one_y, one_c;
-	image_form(s, want_general, &one_y, &one_c);
+	image_form(s, wide, &one_y, &one_c);
 	if (!s.tables_dirty && s.tables_ring.current() && one_y == s.img_one_y && one_c == s.img_one_c)
 	{
-		s.img_want_general = want_general;     // the same image serves this request too
+		s.img_wide = wide;     // the same image serves this request too
 		return 0;
 	}
 	if (int e = fw_flush(s, stream)) return e;
@@ -902,7 +902,7 @@ int upload_tables(State& s, hipStream_t stream, bool want_general)
 	HIP_TRY(s.tables_ring.uploaded(stream));
 	s.tables_dirty = false;
 	s.img_one_y = one_y; s.img_one_c = one_c;
-	s.img_want_general = want_general;
+	s.img_wide = wide;
 	return 0;
 }
 

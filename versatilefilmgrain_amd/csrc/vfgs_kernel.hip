@@ -24,7 +24,9 @@
 //   * a component whose pattern LUT selects one slot for every intensity is served from a packed one-byte-per-sample bank
 //     (ONEY / ONEC kernels, vfgs_layout.h);
 //   * rows of more than 512 grain blocks (8192 luma samples) are walked in parts of 512 blocks, the parameter table refilled
-//     between the parts; the 8-bit output of a 10-bit path (yuv.c:216-258) is a narrowing in the store (OUT8 kernels).
+//     between the parts; the 8-bit output of a 10-bit path (yuv.c:216-258) is a narrowing in the store (OUT8 kernels);
+//   * the frames of a launch lie at a constant pitch behind the plane pointers of the arguments, or anywhere: then their plane
+//     pointers are a table IN the kernel arguments (FrameTable, vfgs_layout.h) and a workgroup reads its frame's with scalar loads.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
