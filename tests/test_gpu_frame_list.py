@@ -133,6 +133,15 @@ def test_list_with_persistent_luma_workgroups(hip, name):
     assert info["persistent_luma_workgroups"] > 0 and info["listed"] == 1, info
 
 
+def test_the_benchmarked_shape_1080p_x32_scattered(hip):
+    """bench.py's `configs` entry: 32 full-size 1080p frames of the default SEI model, every plane an allocation of its own"""
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    frames, _ = T.lcg_frames(1920, 1080, depth, sx, sy, 32)
+    run_list(hip, ora, frames, seed=11)
+    info = hip.last_launch_info()
+    assert info["nframes"] == 32 and info["persistent_luma_workgroups"] > 0 and info["listed"] == 1, info
+
+
 def test_list_of_large_frames_runs_two_fronts(hip):
     """4320p: frames 2m and 2m + 1 of a launch are swept together (frames_per_front == 2) -- through the list as well; an odd count"""
     ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
