@@ -6,6 +6,11 @@
 //   ring K   K x 4 positions per wave through the ring of four: the grain kernel's order        (store u - 1, load u + 4 interleaved)
 //   dbl K    K items per wave, the NEXT item's 4 loads issued before this item's 4 stores       (two register sets of four)
 //   ringw K  as ring, but the store of a position waits until its refill has been issued first (load u + 4, then store u - 1)
+//   ring8 K  the ring with EIGHT register sets (refill eight positions ahead)
+//   split K  even waves only LOAD their K items (and fold them into one register), odd waves only STORE theirs: the same bytes each
+//            way, but no load of any wave ever waits behind a store of the same wave (one in-order vmcnt per wave on gfx9)
+//   stride G  persistent waves (G workgroups per CU), wave w moves items w, w + W, w + 2 W ... (W = all waves): long-lived waves whose
+//            accesses of one iteration form ONE contiguous window of W x 4 KiB, like the item kernel's
 // hipcc --offload-arch=gfx950 -O3 -o tools/bin/walk_probe tools/walk_probe.hip ; tools/bin/walk_probe [MiB]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,9 +26,16 @@ __device__ __forceinline__ u32x4 ld(__amdgpu_buffer_rsrc_t r, uint32_t off) { re
 __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, uint32_t off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 2); }
 
 // MODE 0 item/seq, 1 ring, 2 dbl, 3 ringw; a wave owns K consecutive items (K x 4 KiB); waves of a workgroup own consecutive wave regions
-template <int MODE, int K>
+template <int MODE, int K, int LDS = 0>
 __global__ __launch_bounds__(256) void walk(uint8_t* buf, size_t bytes)
 {
+	// LDS > 0: a static allocation that is never used, only to hold the CU to 160 KiB / LDS workgroups (the grain kernels' occupancy)
+	if constexpr (LDS > 0)
+	{
+		__shared__ uint32_t pad[LDS / 4];
+		if (bytes == 1) pad[threadIdx.x] = 0;      // (never true: keeps the allocation)
+		if (bytes == 2) buf[0] = (uint8_t)pad[threadIdx.x ^ 1];
+	}
 	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const uint32_t lane16 = (threadIdx.x & 63) * 16;
 	const size_t base = wave * (size_t)K * 4096;
@@ -61,6 +73,58 @@ __global__ __launch_bounds__(256) void walk(uint8_t* buf, size_t bytes)
 			}
 		}
 	}
+	else if constexpr (MODE == 4)
+	{
+		// (a pair of waves shares 2 K items: the even one reads all of them, the odd one writes all of them)
+		const size_t pair = wave >> 1;
+		const size_t pbase = pair * (size_t)K * 8192;
+		if (pbase >= bytes) return;
+		const __amdgpu_buffer_rsrc_t pr = rsrc(buf + pbase, (uint32_t)std::min<size_t>(bytes - pbase, (size_t)K * 8192));
+		if (wave & 1)
+		{
+			const u32x4 t = {lane16, 1u, 2u, 3u};
+#pragma unroll 1
+			for (int k = 0; k < 2 * K; k++)
+#pragma unroll
+				for (int u = 0; u < 4; u++) st(pr, k * 4096 + u * 1024 + lane16, t);
+		}
+		else
+		{
+			u32x4 acc = {0u, 0u, 0u, 0u};
+			u32x4 v[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) v[u] = ld(pr, u * 1024 + lane16);
+#pragma unroll 1
+			for (int k = 0; k < 2 * K; k++)
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+				{
+					acc ^= v[u];
+					v[u] = ld(pr, k + 1 < 2 * K ? (k + 1) * 4096 + u * 1024 + lane16 : 0x80000000u);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			if (acc.x == 0x12345u) st(pr, lane16, acc);     // (practically never: keeps the loads alive)
+		}
+	}
+	else if constexpr (MODE == 5)
+	{
+		u32x4 v[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) v[u] = ld(r, u * 1024 + lane16);
+#pragma unroll 1
+		for (int k = 0; k < K; k += 2)
+		{
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const u32x4 t = v[u] + 1u;
+				const uint32_t here = k * 4096 + u * 1024 + lane16;
+				st(r, here, t);
+				v[u] = ld(r, k + 2 < K ? here + 8192 : 0x80000000u);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	}
 	else
 	{
 		u32x4 a[4], b[4];
@@ -86,19 +150,57 @@ __global__ __launch_bounds__(256) void walk(uint8_t* buf, size_t bytes)
 	}
 }
 
-template <int MODE, int K>
+__global__ __launch_bounds__(256) void walk_stride(uint8_t* buf, size_t bytes)
+{
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	const uint32_t lane16 = (threadIdx.x & 63) * 16;
+	for (size_t base = wave * 4096; base < bytes; base += nwaves * 4096)
+	{
+		const __amdgpu_buffer_rsrc_t r = rsrc(buf + base, (uint32_t)std::min<size_t>(bytes - base, 4096));
+		u32x4 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) v[u] = ld(r, u * 1024 + lane16);
+#pragma unroll
+		for (int u = 0; u < 4; u++) st(r, u * 1024 + lane16, v[u] + 1u);
+	}
+}
+
+static double run_stride(uint8_t* buf, size_t bytes, int reps, int wg_per_cu)
+{
+	hipDeviceProp_t prop;
+	hipGetDeviceProperties(&prop, 0);
+	const unsigned grid = (unsigned)(prop.multiProcessorCount * wg_per_cu);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	for (int i = 0; i < 3; i++) hipLaunchKernelGGL(walk_stride, dim3(grid), dim3(256), 0, 0, buf, bytes);
+	std::vector<float> ms;
+	for (int rep = 0; rep < reps; rep++)
+	{
+		hipEventRecord(e0);
+		hipLaunchKernelGGL(walk_stride, dim3(grid), dim3(256), 0, 0, buf, bytes);
+		hipEventRecord(e1);
+		hipEventSynchronize(e1);
+		float t;
+		hipEventElapsedTime(&t, e0, e1);
+		ms.push_back(t);
+	}
+	std::sort(ms.begin(), ms.end());
+	return 2.0 * bytes / (ms[ms.size() / 2] * 1e-3) / 1e9;
+}
+
+template <int MODE, int K, int LDS = 0>
 static double run(uint8_t* buf, size_t bytes, int reps)
 {
 	const size_t waves = (bytes + (size_t)K * 4096 - 1) / ((size_t)K * 4096);
 	const unsigned grid = (unsigned)((waves + 3) / 4);
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	for (int i = 0; i < 3; i++) hipLaunchKernelGGL((walk<MODE, K>), dim3(grid), dim3(256), 0, 0, buf, bytes);
+	for (int i = 0; i < 3; i++) hipLaunchKernelGGL((walk<MODE, K, LDS>), dim3(grid), dim3(256), 0, 0, buf, bytes);
 	std::vector<float> ms;
 	for (int rep = 0; rep < reps; rep++)
 	{
 		hipEventRecord(e0);
-		hipLaunchKernelGGL((walk<MODE, K>), dim3(grid), dim3(256), 0, 0, buf, bytes);
+		hipLaunchKernelGGL((walk<MODE, K, LDS>), dim3(grid), dim3(256), 0, 0, buf, bytes);
 		hipEventRecord(e1);
 		hipEventSynchronize(e1);
 		float t;
@@ -126,6 +228,18 @@ int main(int argc, char** argv)
 		LINE("ring", 1, 2) LINE("ring", 1, 4) LINE("ring", 1, 16)
 		LINE("ringw", 3, 4) LINE("ringw", 3, 16)
 		LINE("dbl", 2, 2) LINE("dbl", 2, 4) LINE("dbl", 2, 16)
+		for (int g : {1, 2, 3, 4, 8}) { const double gb = run_stride(buf, bytes, reps, g); printf("%-10s G=%-3d %8.1f  %.4f\n", "stride", g, gb, gb / 8000.0); fflush(stdout); }
+		LINE("ring8", 5, 2) LINE("ring8", 5, 4) LINE("ring8", 5, 16)
+		LINE("split", 4, 1) LINE("split", 4, 2) LINE("split", 4, 4) LINE("split", 4, 16)
+	}
+	// the same streams at the occupancy of the grain kernels: 160 KiB / LDS workgroups of four waves per CU
+#define LINEL(name, MODE, K, LDS) { const double g = run<MODE, K, LDS>(buf, bytes, reps); printf("%-10s K=%-3d %2d waves/CU %8.1f  %.4f\n", name, K, 4 * (163840 / LDS), g, g / 8000.0); fflush(stdout); }
+	for (int round = 0; round < 2; round++)
+	{
+		LINEL("item", 0, 1, 20480) LINEL("item", 0, 1, 27304) LINEL("item", 0, 1, 32768) LINEL("item", 0, 1, 40960) LINEL("item", 0, 1, 54608) LINEL("item", 0, 1, 81920)
+		LINEL("ring", 1, 2, 20480) LINEL("ring", 1, 2, 27304) LINEL("ring", 1, 2, 32768) LINEL("ring", 1, 2, 40960) LINEL("ring", 1, 2, 54608)
+		LINEL("split", 4, 4, 20480) LINEL("split", 4, 4, 40960) LINEL("split", 4, 4, 81920) LINEL("ring8", 5, 4, 40960) LINEL("ring8", 5, 4, 54608)
+		LINEL("ring", 1, 4, 20480) LINEL("ring", 1, 4, 27304) LINEL("ring", 1, 4, 32768) LINEL("ring", 1, 4, 40960) LINEL("ring", 1, 4, 54608) LINEL("ring", 1, 4, 81920)
 	}
 	return 0;
 }
