@@ -150,6 +150,56 @@ __global__ __launch_bounds__(256) void walk(uint8_t* buf, size_t bytes)
 	}
 }
 
+// the ring over regions of any size and place: wave w walks `region` bytes (a multiple of 1 KiB; the last group may be partly out of range: masked
+// by the descriptor) from offset + w * pitch -- the grain kernel's rows (region = pitch = 15 KiB at 4320p) and what alignment is worth
+__global__ __launch_bounds__(256) void walk_rows(uint8_t* buf, size_t bytes, uint32_t region, size_t pitch, size_t offset)
+{
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t lane16 = (threadIdx.x & 63) * 16;
+	const size_t base = offset + wave * pitch;
+	if (base + region > bytes) return;
+	const __amdgpu_buffer_rsrc_t r = rsrc(buf + base, region);
+	const int groups = (int)((region + 4095) / 4096);
+	u32x4 v[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) v[u] = ld(r, u * 1024 + lane16);
+#pragma unroll 1
+	for (int k = 0; k < groups; k++)
+	{
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const u32x4 t = v[u] + 1u;
+			const uint32_t here = k * 4096 + u * 1024 + lane16;
+			st(r, here, t);                                                   // (behind the region's end: dropped)
+			v[u] = ld(r, k + 1 < groups ? here + 4096 : 0x80000000u);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+}
+
+static double run_rows(uint8_t* buf, size_t bytes, int reps, uint32_t region, size_t pitch, size_t offset)
+{
+	const size_t waves = (bytes - offset) / pitch;
+	const unsigned grid = (unsigned)((waves + 3) / 4);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	for (int i = 0; i < 3; i++) hipLaunchKernelGGL(walk_rows, dim3(grid), dim3(256), 0, 0, buf, bytes, region, pitch, offset);
+	std::vector<float> ms;
+	for (int rep = 0; rep < reps; rep++)
+	{
+		hipEventRecord(e0);
+		hipLaunchKernelGGL(walk_rows, dim3(grid), dim3(256), 0, 0, buf, bytes, region, pitch, offset);
+		hipEventRecord(e1);
+		hipEventSynchronize(e1);
+		float t;
+		hipEventElapsedTime(&t, e0, e1);
+		ms.push_back(t);
+	}
+	std::sort(ms.begin(), ms.end());
+	return 2.0 * (double)waves * region / (ms[ms.size() / 2] * 1e-3) / 1e9;
+}
+
 __global__ __launch_bounds__(256) void walk_stride(uint8_t* buf, size_t bytes)
 {
 	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -229,6 +279,13 @@ int main(int argc, char** argv)
 		LINE("ringw", 3, 4) LINE("ringw", 3, 16)
 		LINE("dbl", 2, 2) LINE("dbl", 2, 4) LINE("dbl", 2, 16)
 		for (int g : {1, 2, 3, 4, 8}) { const double gb = run_stride(buf, bytes, reps, g); printf("%-10s G=%-3d %8.1f  %.4f\n", "stride", g, gb, gb / 8000.0); fflush(stdout); }
+		LINE("ring", 1, 3) LINE("ring", 1, 5) LINE("ring", 1, 6) LINE("ring", 1, 7) LINE("ring", 1, 8) LINE("ring", 1, 15)      // (regions that are not powers of two)
+		struct { const char* name; uint32_t region; size_t pitch, offset; } rows[] = {
+			{"4K/4K", 4096, 4096, 0}, {"4K/4K+1K", 4096, 4096, 1024}, {"4K/4K+256", 4096, 4096, 256}, {"3K/4K", 3072, 4096, 0}, {"4K/5K", 4096, 5120, 0},
+			{"8K/8K", 8192, 8192, 0}, {"7.5K/7.5K", 7680, 7680, 0}, {"7.5K/8K", 7680, 8192, 0},
+			{"16K/16K", 16384, 16384, 0}, {"15K/15K", 15360, 15360, 0}, {"15K/16K", 15360, 16384, 0}, {"16K/16K+1K", 16384, 16384, 1024}, {"16K/17K", 16384, 17408, 0},
+			{"32K/32K", 32768, 32768, 0}, {"30K/30K", 30720, 30720, 0}, {"30K/32K", 30720, 32768, 0}, {"3.75K/3.75K", 3840, 3840, 0}, {"3.75K/4K", 3840, 4096, 0}};
+		for (auto& q : rows) { const double gb = run_rows(buf, bytes, reps, q.region, q.pitch, q.offset); printf("%-10s %-12s %8.1f  %.4f\n", "rows", q.name, gb, gb / 8000.0); fflush(stdout); }
 		LINE("ring8", 5, 2) LINE("ring8", 5, 4) LINE("ring8", 5, 16)
 		LINE("split", 4, 1) LINE("split", 4, 2) LINE("split", 4, 4) LINE("split", 4, 16)
 	}
