@@ -266,11 +266,11 @@ def bench_configs(h, stream, steps_ms=60.0, cpu_seconds=2.5):
     return out
 
 
-def gpu_numa_cpus(index):
+def gpu_numa_cpus(index, sysfs="/sys"):
     """CPUs of the NUMA node GPU `index` (HIP order) hangs off, from sysfs -- nothing here touches the GPU.  None if it cannot be told."""
     try:
         nodes = []
-        base = Path("/sys/class/kfd/kfd/topology/nodes")
+        base = Path(sysfs) / "class/kfd/kfd/topology/nodes"
         for d in sorted(base.iterdir(), key=lambda p: int(p.name)):
             try:      # (a container sees only the properties of the GPUs it was given: the others are not this process's devices)
                 props = dict(l.split() for l in (d / "properties").read_text().splitlines() if len(l.split()) == 2)
@@ -286,7 +286,7 @@ def gpu_numa_cpus(index):
         loc, dom = int(p["location_id"]), int(p.get("domain", "0"))
         bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
         cpus = set()
-        for part in (Path("/sys/bus/pci/devices") / bdf / "local_cpulist").read_text().strip().split(","):
+        for part in (Path(sysfs) / "bus/pci/devices" / bdf / "local_cpulist").read_text().strip().split(","):
             a, _, b = part.partition("-")
             cpus.update(range(int(a), int(b or a) + 1))
         return bdf, cpus

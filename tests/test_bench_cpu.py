@@ -39,3 +39,26 @@ def test_recorded_traffic_names_its_sources():
     if rec["kernel_sha16"] != bench.kernel_sha():
         warnings.warn("profiles/hbm_traffic.json was recorded for other sources than the tree's: bench.py will say \"stale\": true "
                       "(re-run tools/gpu_bench_profile.sh after the last kernel-affecting change)")
+
+
+def test_rank_pinning_reads_the_gpus_numa_cpus_from_sysfs(tmp_path, monkeypatch):
+    """bench.py pins every rank to the CPUs next to its GPU before the first GPU call: KFD topology node -> PCI address ->
+    local_cpulist.  A container sees only the properties of the GPUs it was given (the others: permission denied)."""
+    import bench
+    nodes = tmp_path / "class/kfd/kfd/topology/nodes"
+    for i, (simd, loc) in enumerate([(0, 0), (0, 0), (1024, 0x0d00), (1024, 0x2600)]):      # two CPU nodes, two GPUs
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count 64\nsimd_count {simd}\nlocation_id {loc}\ndomain 0\n")
+    (nodes / "4").mkdir()                               # a GPU of another container: unreadable
+    (nodes / "4" / "properties").mkdir()
+    for bdf, cpus in (("0000:0d:00.0", "0-63,128-191"), ("0000:26:00.0", "64-127,192-255")):
+        d = tmp_path / "bus/pci/devices" / bdf
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text(cpus + "\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    bdf, cpus = bench.gpu_numa_cpus(1, sysfs=str(tmp_path))
+    assert bdf == "0000:26:00.0" and cpus == set(range(64, 128)) | set(range(192, 256))
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")      # the process sees only the second GPU, as its device 0
+    assert bench.gpu_numa_cpus(0, sysfs=str(tmp_path))[0] == "0000:26:00.0"
+    assert bench.gpu_numa_cpus(3, sysfs=str(tmp_path)) is None and bench.gpu_numa_cpus(0, sysfs=str(tmp_path / "nowhere")) is None
