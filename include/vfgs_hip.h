@@ -166,6 +166,12 @@ int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV,
 typedef struct vfgs_hip_frame_ptrs { void* Y; void* U; void* V; } vfgs_hip_frame_ptrs;
 int vfgs_hip_add_grain_frame_list_dev(const vfgs_hip_frame_ptrs* frames, unsigned nframes, unsigned width, unsigned height,
                                       unsigned stride, unsigned cstride, void* stream);
+/* ... lines [part_y, part_y + part_height) of every listed frame only (what one rank of a stripe split runs on its stripes of a
+ * pool of frames): frames[f].Y / .U / .V address line part_y (chroma row part_y / csuby) of frame f, part_y a multiple of 16;
+ * the seed registers advance as for whole frames of `frame_height` lines (vfgs_hip_add_grain_frames_part_dev). */
+int vfgs_hip_add_grain_frame_list_part_dev(const vfgs_hip_frame_ptrs* frames, unsigned nframes, unsigned width,
+                                           unsigned frame_height, unsigned part_y, unsigned part_height,
+                                           unsigned stride, unsigned cstride, void* stream);
 int vfgs_hip_add_grain_frame_list_copy_dev(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes,
                                            unsigned width, unsigned height, unsigned stride, unsigned cstride, void* stream);
 int vfgs_hip_add_grain_frame_list_copy8_dev(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes,

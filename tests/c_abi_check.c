@@ -16,7 +16,7 @@ int main(void)
 		(void (*)(void))vfgs_hip_init, (void (*)(void))vfgs_hip_shutdown, (void (*)(void))vfgs_hip_reset_state,
 		(void (*)(void))vfgs_hip_add_grain_stripe_dev, (void (*)(void))vfgs_hip_add_grain_frame_dev, (void (*)(void))vfgs_hip_add_grain_frame_part_dev,
 		(void (*)(void))vfgs_hip_add_grain_frames_dev, (void (*)(void))vfgs_hip_add_grain_frames_part_dev, (void (*)(void))vfgs_hip_add_grain_copy_dev,
-		(void (*)(void))vfgs_hip_add_grain_copy8_dev, (void (*)(void))vfgs_hip_add_grain_frame_list_dev, (void (*)(void))vfgs_hip_add_grain_frame_list_copy_dev,
+		(void (*)(void))vfgs_hip_add_grain_copy8_dev, (void (*)(void))vfgs_hip_add_grain_frame_list_dev, (void (*)(void))vfgs_hip_add_grain_frame_list_part_dev, (void (*)(void))vfgs_hip_add_grain_frame_list_copy_dev,
 		(void (*)(void))vfgs_hip_add_grain_frame_list_copy8_dev, (void (*)(void))vfgs_hip_get_seed_state, (void (*)(void))vfgs_hip_get_luts, (void (*)(void))vfgs_hip_get_params, (void (*)(void))vfgs_hip_last_error,
 		(void (*)(void))vfgs_hip_last_error_string, (void (*)(void))vfgs_hip_timer_begin, (void (*)(void))vfgs_hip_timer_end, (void (*)(void))vfgs_hip_device_info,
 		(void (*)(void))vfgs_hip_dev_build, (void (*)(void))vfgs_hip_init_devices, (void (*)(void))vfgs_hip_overlap_begin, (void (*)(void))vfgs_hip_overlap_end, (void (*)(void))vfgs_hip_get_stream_stats, (void (*)(void))vfgs_hip_line_lookahead, (void (*)(void))vfgs_hip_declare_frame,

@@ -151,6 +151,37 @@ def test_list_of_large_frames_runs_two_fronts(hip):
     assert info["frames_per_front"] == 2 and info["listed"] == 1, info
 
 
+@pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_420", "fgs_sei_10_444"])
+def test_list_of_stripes_equals_the_stripe_split_of_every_frame(hip, name):
+    """What one rank of an N-way stripe split runs on a pool of frames: lines [32, 64 + 6) of every listed frame (the last block row
+    partial), pointers at line 32, registers advancing as for whole frames.  Three ranks' parts together = the whole frames."""
+    ora, (depth, sx, sy) = program(hip, name)
+    W, H = 1032, 150
+    frames = [garbage_frame(W, H, depth, sx, sy, 40 + i) for i in range(5)]
+    want = [f.copy() for f in frames]
+    for w in want:
+        ora.add_grain_frame(w)
+    dev = scattered(frames, 12)
+    f0 = frames[0]
+    st0 = None
+    for py, ph in ((0, 32), (32, 38), (70, 80)):          # (the second part ends inside a block row, the third begins inside it: 70 is not a multiple of 16 -> refused)
+        if py & 15:
+            from versatilefilmgrain_amd.hw import VfgsHipError
+            with pytest.raises(VfgsHipError, match="multiple of 16"):
+                hip.add_grain_frame_list_part_dev([d.ptrs(py) for d in dev], W, H, py, ph, f0.stride, f0.cstride, stream_ptr())
+            continue
+    # a proper three-way split: block rows 0-1, 2-4, 5-9 (150 lines = 9 block rows + 6 lines)
+    for rank, (py, ph) in enumerate(((0, 32), (32, 48), (80, 70))):
+        program_state = program(hip, name)                # every rank starts from the same programmed state and seed
+        hip.add_grain_frame_list_part_dev([d.ptrs(py) for d in dev], W, H, py, ph, f0.stride, f0.cstride, stream_ptr())
+        st = hip.seed_state()
+        assert st0 is None or st == st0                   # all ranks end with the same registers: those of whole frames
+        st0 = st
+    assert st0 == ora.seed_state()
+    for i, (d, w) in enumerate(zip(dev, want)):
+        assert d.download().equal_all(w), i
+
+
 @pytest.mark.parametrize("name", ["fgs_sei_10_420", "fgs_afgs1_test1_8_444"])
 def test_list_out_of_place(hip, name):
     """src[f] -> dst[f]; one pair in place (src == dst); the sources stay as they were"""

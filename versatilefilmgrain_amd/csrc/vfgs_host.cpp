@@ -2222,8 +2222,9 @@ int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned wi
 // Frames anywhere in device memory (vfgs_hip.h): validated as a whole before anything moves, then launched in chunks of
 // kListFrames frames whose plane pointers travel in the kernel arguments.
 static int run_frame_list(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes, unsigned width, unsigned height,
-                          unsigned stride, unsigned cstride, hipStream_t stream, DstGeom dg)
+                          unsigned stride, unsigned cstride, hipStream_t stream, DstGeom dg, unsigned part_y = 0, unsigned part_h = ~0u)
 {
+	if (part_h == ~0u) part_h = height;
 	State& s = S();
 	if (int e = ensure_init(-1)) return e;
 	if (nframes == 0) return 0;
@@ -2250,7 +2251,7 @@ static int run_frame_list(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_p
 			ft.src[0][k] = (const uint8_t*)a.Y; ft.src[1][k] = (const uint8_t*)a.U; ft.src[2][k] = (const uint8_t*)a.V;
 			ft.dst[0][k] = (uint8_t*)b.Y; ft.dst[1][k] = (uint8_t*)b.U; ft.dst[2][k] = (uint8_t*)b.V;
 		}
-		if (int e = run_device(src[f0].Y, src[f0].U, src[f0].V, dst[f0].Y, dst[f0].U, dst[f0].V, width, 0, height, 0, height, stride, cstride,
+		if (int e = run_device(src[f0].Y, src[f0].U, src[f0].V, dst[f0].Y, dst[f0].U, dst[f0].V, width, 0, height, part_y, part_h, stride, cstride,
 		                       n, 0, 0, stream, dg, &ft))
 			return e;
 	}
@@ -2263,6 +2264,16 @@ int vfgs_hip_add_grain_frame_list_dev(const vfgs_hip_frame_ptrs* frames, unsigne
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	return run_frame_list(frames, frames, nframes, width, height, stride, cstride, pick_stream(stream), DstGeom());
+}
+
+int vfgs_hip_add_grain_frame_list_part_dev(const vfgs_hip_frame_ptrs* frames, unsigned nframes, unsigned width, unsigned frame_height,
+                                           unsigned part_y, unsigned part_height, unsigned stride, unsigned cstride, void* stream)
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	S().gen++;
+	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
+	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	return run_frame_list(frames, frames, nframes, width, frame_height, stride, cstride, pick_stream(stream), DstGeom(), part_y, part_height);
 }
 
 int vfgs_hip_add_grain_frame_list_copy_dev(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes, unsigned width,

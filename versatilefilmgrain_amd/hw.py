@@ -105,6 +105,7 @@ def load(path: Path | None = None) -> C.CDLL:
                                                  C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     fp = C.POINTER(FramePtrs)
     lib.vfgs_hip_add_grain_frame_list_dev.argtypes = [fp, u, u, u, u, u, vp]
+    lib.vfgs_hip_add_grain_frame_list_part_dev.argtypes = [fp, u, u, u, u, u, u, u, vp]
     lib.vfgs_hip_add_grain_frame_list_copy_dev.argtypes = [fp, fp, u, u, u, u, u, vp]
     lib.vfgs_hip_add_grain_frame_list_copy8_dev.argtypes = [fp, fp, u, u, u, u, u, u, u, vp]
     lib.vfgs_hip_get_seed_state.argtypes = [vp]
@@ -153,7 +154,7 @@ EXPORTS = [
     "vfgs_add_grain_stripe", "vfgs_hip_init", "vfgs_hip_shutdown", "vfgs_hip_reset_state",
     "vfgs_hip_add_grain_stripe_dev", "vfgs_hip_add_grain_frame_dev", "vfgs_hip_add_grain_frame_part_dev",
     "vfgs_hip_add_grain_frames_dev", "vfgs_hip_add_grain_frames_part_dev", "vfgs_hip_add_grain_copy_dev",
-    "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_add_grain_frame_list_dev", "vfgs_hip_add_grain_frame_list_copy_dev",
+    "vfgs_hip_add_grain_copy8_dev", "vfgs_hip_add_grain_frame_list_dev", "vfgs_hip_add_grain_frame_list_part_dev", "vfgs_hip_add_grain_frame_list_copy_dev",
     "vfgs_hip_add_grain_frame_list_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
     "vfgs_hip_dev_build", "vfgs_hip_init_devices", "vfgs_hip_overlap_begin", "vfgs_hip_overlap_end", "vfgs_hip_get_stream_stats", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
@@ -242,6 +243,11 @@ class VfgsHip:
     def add_grain_frame_list_dev(self, frames, width, height, stride, cstride, stream=0):
         """Frames anywhere in device memory, one launch per 32 of them (include/vfgs_hip.h)."""
         self._ck(self.lib.vfgs_hip_add_grain_frame_list_dev(self.frame_list(frames), len(frames), width, height, stride, cstride, stream))
+
+    def add_grain_frame_list_part_dev(self, frames, width, frame_height, part_y, part_height, stride, cstride, stream=0):
+        """Lines [part_y, part_y + part_height) of every listed frame; the pointers address line part_y; seeds advance as for whole frames."""
+        self._ck(self.lib.vfgs_hip_add_grain_frame_list_part_dev(self.frame_list(frames), len(frames), width, frame_height, part_y, part_height,
+                                                                 stride, cstride, stream))
 
     def add_grain_frame_list_copy_dev(self, src, dst, width, height, stride, cstride, stream=0):
         assert len(src) == len(dst)
