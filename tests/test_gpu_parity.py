@@ -656,3 +656,22 @@ def test_line_api_frame_height_promised_through_the_environment(hip, monkeypatch
         assert hip.seed_state() == ora.seed_state()
     n2 = hip.last_launch_info()["launches"]
     assert n2 - n1 < 40, n2 - n1    # two frames of 540 lines: a few single lines + a handful of stripes each
+
+
+def test_line_api_promised_height_with_buffers_of_different_pitches(hip, monkeypatch):
+    """VFGS_HIP_FRAME_HEIGHT and a walk through ANOTHER buffer of the same width but a smaller row pitch: the pitches the previous
+    walk showed prove nothing about this buffer -- the library learns them again from its first lines before it reads ahead
+    (with the stale pitches it would snapshot rows beyond the smaller allocation).  Results and registers as ever."""
+    ora, (depth, sx, sy) = program(hip, "fgs_sei_10_420")
+    w, h = 1000, 200
+    monkeypatch.setenv("VFGS_HIP_FRAME_HEIGHT", str(h))
+    rng = np.random.default_rng(77)
+    for i, (stride, cstride) in enumerate([(1280, 640), (1024, 512), (1024, 512), (1152, 576), (1024, 512)]):
+        a = T.Frame(w, h, depth, sx, sy, stride=stride, cstride=cstride)
+        for p in a.planes():
+            p[...] = rng.integers(0, 1024, p.shape).astype(a.dtype)
+        b = a.copy()
+        _line_loop(hip, a, sy)
+        _line_loop(ora, b, sy)
+        assert a.equal_all(b), i
+        assert hip.seed_state() == ora.seed_state()
