@@ -155,7 +155,7 @@ def fill_ramp(t, depth, g, frame, rows, cols):
     t.view(rows, cols).copy_((base + noise).clamp(0, (1 << depth) - 1).to(t.dtype))
 
 
-def bench_configs(h, stream, steps_ms=60.0, cpu_seconds=2.5):
+def bench_configs(h, stream, steps_ms=60.0, cpu_seconds=2.5, out=None):
     """BASELINE.json configs[0..3] (+ the headline workload with natural-like content) on this GPU: device-resident frames, in place,
     plain stream, HIP events on the launching stream; one post-timing launch of the timed shape per entry is compared with the
     oracle, frame by frame; the reference's CPU path is timed beside every size (one core, a bounded sample)."""
@@ -163,7 +163,7 @@ def bench_configs(h, stream, steps_ms=60.0, cpu_seconds=2.5):
     import numpy as np
     import torch
     import vfgs_testlib as T
-    out = []
+    out = [] if out is None else out     # (the caller's list: entries that finished survive an exception in a later one)
     for name, w, hh, depth, (sx, sy), trace, variants in CONFIGS:
         rec = T.load_trace(trace)
         dt = torch.int16 if depth > 8 else torch.uint8
@@ -278,7 +278,9 @@ def gpu_numa_cpus(index, sysfs="/sys"):
                 continue
             if int(props.get("simd_count", "0")) > 0:
                 nodes.append(props)
-        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        # ROCR_VISIBLE_DEVICES filters what the runtime sees; HIP_VISIBLE_DEVICES then renumbers THAT list, and
+        # CUDA_VISIBLE_DEVICES is only HIP's alias for it (launchers often set both: applied once, HIP takes precedence)
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES" if os.environ.get("HIP_VISIBLE_DEVICES") else "CUDA_VISIBLE_DEVICES"):
             vis = os.environ.get(var)
             if vis and all(x.strip().isdigit() for x in vis.split(",")):
                 nodes = [nodes[int(x)] for x in vis.split(",") if int(x) < len(nodes)]
@@ -359,6 +361,14 @@ def main():
     affinity = pin_to_gpu(local) if world > 1 else "not pinned (one rank)"      # before anything touches the GPU
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local)
+    if world > 1 and not args.rehearse_on_one_gpu:
+        # (KFD node order was assumed to be HIP's device order: say so if the device the runtime gave this rank sits elsewhere)
+        try:
+            got, real = gpu_numa_cpus(local), int(torch.cuda.get_device_properties(local).pci_bus_id)
+            if got and real != int(got[0].split(":")[1], 16):
+                affinity += f"; MISMATCH: sysfs says {got[0]}, the runtime's device {local} is on bus {real:02x}"
+        except Exception:      # noqa: BLE001  (an attribute this torch build lacks: nothing to cross-check)
+            pass
     if world > 1:
         # The data path has no collective (stripes are independent, DESIGN.md "multi-GPU"): the process group only
         # carries the barrier around the timed region and the max / gather of the timings -- host-side, over gloo.
@@ -585,12 +595,18 @@ def main():
             "parity_checked": parity,
         }
         if world == 1 and not args.no_configs:
-            # (a failure of this leg -- memory, a missing fixture -- must not cost the headline its line: it is recorded instead)
+            # A failure of this leg for want of a RESOURCE (device or host memory, a fixture that did not travel) must not cost the
+            # headline its line: it is recorded, and the entries that had finished stay.  Anything else -- an error from the library
+            # or from HIP in the middle of an entry -- is a failed run: recorded too, and the line loses its parity claim.
+            import torch
+            out["configs"] = []
             try:
-                out["configs"] = bench_configs(h, stream, cpu_seconds=0.0 if args.no_cpu else 2.5)
-            except Exception as ex:      # noqa: BLE001
-                out["configs"] = []
+                bench_configs(h, stream, cpu_seconds=0.0 if args.no_cpu else 2.5, out=out["configs"])
+            except (torch.cuda.OutOfMemoryError, MemoryError, FileNotFoundError) as ex:
                 out["configs_error"] = f"{type(ex).__name__}: {ex}"
+            except Exception as ex:      # noqa: BLE001
+                out["configs_error"] = f"{type(ex).__name__}: {ex}"
+                parity = False
             if not all(c["parity_checked"] for c in out["configs"]):
                 parity = False
         if world == 1 and not args.no_cpu:
@@ -598,8 +614,9 @@ def main():
         if parity is False:
             # a kernel that produced wrong bytes gets no benchmark line: the numbers are withheld and the exit code says so
             bad_cfg = [c["workload"] + f" x{c['frames_per_launch']} ({c['frame_layout']})" for c in out.get("configs", []) if not c["parity_checked"]]
-            out = {"metric": out["metric"], "error": "parity failure: output differs from the oracle", "parity_checked": False,
-                   "n_gpus": world, "failed_configs": bad_cfg}
+            out = {"metric": out["metric"], "error": "parity failure: output differs from the oracle" if "configs_error" not in out or bad_cfg
+                   else "the configs leg failed: " + out["configs_error"], "parity_checked": False,
+                   "n_gpus": world, "failed_configs": bad_cfg, **({"configs_error": out["configs_error"]} if "configs_error" in out else {})}
         print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.destroy_process_group()

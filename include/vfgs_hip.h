@@ -160,8 +160,10 @@ int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV,
  * is host memory, read during the call only (the pointers travel in the kernel arguments: nothing to keep alive, no copy queued
  * in front of the launch).  A single frame per launch runs at 0.23 (1080p) / 0.49 (2160p) / 0.61 (4320p) of the HBM peak, the
  * same frames handed over 32 / 16 / 8 at a time at 0.70 / 0.76 / 0.72 (a launch costs 5 us of fill and drain).  All frames of
- * a call are in flight together: a destination plane may appear only once in the list (refused otherwise), and planes of
- * different frames must not overlap.  _copy: out of place, src[f] -> dst[f], same geometry (src[f] == dst[f] allowed);
+ * a call are in flight together, so the call refuses (error 18, nothing changed) destination planes that share bytes -- the
+ * same plane listed twice, or two whose rows overlap -- and, in the _copy forms, a source plane that shares bytes with the
+ * destination of ANOTHER frame (consecutive calls would read it grained or not, deterministically; one launch would not).
+ * _copy: out of place, src[f] -> dst[f], same geometry (a plane of src[f] may BE the plane of dst[f]: in place);
  * _copy8: 10-bit source, 8-bit destination as vfgs_hip_add_grain_copy8_dev.  A refused call changes nothing. */
 typedef struct vfgs_hip_frame_ptrs { void* Y; void* U; void* V; } vfgs_hip_frame_ptrs;
 int vfgs_hip_add_grain_frame_list_dev(const vfgs_hip_frame_ptrs* frames, unsigned nframes, unsigned width, unsigned height,

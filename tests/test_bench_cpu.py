@@ -62,3 +62,10 @@ def test_rank_pinning_reads_the_gpus_numa_cpus_from_sysfs(tmp_path, monkeypatch)
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")      # the process sees only the second GPU, as its device 0
     assert bench.gpu_numa_cpus(0, sysfs=str(tmp_path))[0] == "0000:26:00.0"
     assert bench.gpu_numa_cpus(3, sysfs=str(tmp_path)) is None and bench.gpu_numa_cpus(0, sysfs=str(tmp_path / "nowhere")) is None
+    # CUDA_VISIBLE_DEVICES is HIP's alias for HIP_VISIBLE_DEVICES and launchers set both: one filter, not two in a row
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "1")
+    assert bench.gpu_numa_cpus(0, sysfs=str(tmp_path))[0] == "0000:26:00.0"
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert bench.gpu_numa_cpus(0, sysfs=str(tmp_path))[0] == "0000:26:00.0"      # ... and alone it still counts
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1,0")                              # the runtime's own filter comes first
+    assert bench.gpu_numa_cpus(0, sysfs=str(tmp_path))[0] == "0000:0d:00.0"       # CUDA's "1" of ROCR's (second, first) = the first GPU

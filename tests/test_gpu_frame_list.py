@@ -273,6 +273,15 @@ def test_refused_lists_change_nothing(hip):
         hip.add_grain_frame_list_dev([ptrs[0], ptrs[1], ptrs[0]], f0.width, f0.height, f0.stride, f0.cstride, stream_ptr())
     with pytest.raises(VfgsHipError, match="null plane"):
         hip.add_grain_frame_list_dev([ptrs[0], (ptrs[1][0], 0, ptrs[1][2])], f0.width, f0.height, f0.stride, f0.cstride, stream_ptr())
+    # destination planes that share rows without being the same pointer (frame 1's luma begins 16 rows into frame 0's) ...
+    with pytest.raises(VfgsHipError, match="overlap"):
+        hip.add_grain_frame_list_dev([ptrs[0], (dev[0].ptrs(16)[0], ptrs[1][1], ptrs[1][2])], f0.width, f0.height, f0.stride, f0.cstride, stream_ptr())
+    # ... and, out of place, a source that is ANOTHER frame's destination: one launch would read it grained or not by chance
+    with pytest.raises(VfgsHipError, match="shares bytes"):
+        hip.add_grain_frame_list_copy_dev([ptrs[0], ptrs[1]], [ptrs[1], ptrs[2]], f0.width, f0.height, f0.stride, f0.cstride, stream_ptr())
+    # a part whose height wraps 32 bits is a part that exceeds the frame (it used to pass the check and select the whole frame)
+    with pytest.raises(VfgsHipError, match="exceeds the frame"):
+        hip.add_grain_frame_list_part_dev(ptrs, f0.width, f0.height, 16, 0xFFFFFFFF, f0.stride, f0.cstride, stream_ptr())
     with pytest.raises(VfgsHipError, match="16-byte aligned"):
         hip.add_grain_frame_list_dev([ptrs[0], (ptrs[1][0] + 8, ptrs[1][1], ptrs[1][2])], f0.width, f0.height, f0.stride, f0.cstride, stream_ptr())
     with pytest.raises(VfgsHipError, match="stride"):
