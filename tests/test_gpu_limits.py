@@ -174,3 +174,42 @@ def test_one_pattern_form_with_extreme_pattern_values(hip, name, lowest):
         ora.add_grain_frame(want)
         assert d.download().equal_all(want)
     assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name", ["fgs_afgs1_test1_8_444", "fgs_afgs1_test1_8_420", "fgs_sei_8_422", "fgs_afgs1_test1_8_440"])
+@pytest.mark.parametrize("shift", [2, 5, 7])
+def test_packed_16_bit_form_at_its_limit(hip, name, shift):
+    """8-bit one-pattern components multiply pattern and scale in 16 bits, two samples per instruction (vfgs_layout.h "packed
+    16-bit form"; vfgs_hw.c:263): exact while max(scale) * 127 + 2^(shift-1) <= 32767, and the host checks exactly that when it
+    digests the LUT -- a LUT beyond it keeps the general form.  Patterns of +-127 everywhere, scale LUTs whose maximum sits at
+    the limit, one below and one above it and at 255, for the smallest, the usual and the largest shift: always the oracle's bytes,
+    and the kernel name says which form ran."""
+    from gpu_util import DevFrame, stream_ptr
+    depth, sx, sy = T.trace_geometry(T.load_trace(name))
+    eff = shift + 6                                   # vfgs_hw.c:349 at 8 bit
+    limit = (32767 - (1 << (eff - 1))) // 127         # the largest scale the 16-bit product can hold
+    rng = np.random.default_rng(shift)
+    for top in sorted({min(limit, 255), min(limit, 255) - 1, min(limit + 1, 255), 255}):
+        ora = program(hip, name)
+        for obj in (hip, ora):
+            obj.set_scale_shift(shift)
+        P = rng.choice(np.array([-127, 127, 127, -127, 126, -1, 0, 1], dtype=np.int8), size=4096).astype(np.int8)
+        lut = rng.integers(0, top + 1, 256).astype(np.uint8)
+        lut[rng.integers(0, 256, 40)] = top           # the maximum is met often, by any intensity
+        for obj in (hip, ora):
+            for k in range(2):
+                obj.set_luma_pattern(k, P.tobytes())
+                obj.set_chroma_pattern(k, P[::-1].tobytes())
+            for c in range(3):
+                obj.set_scale_lut(c, lut.tobytes())
+        f, _ = T.lcg_frames(1936, 112, depth, sx, sy, 2, state=top)
+        for fr in f:
+            want = fr.copy()
+            d = DevFrame(fr)
+            hip.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), fr.width, fr.height, fr.stride, fr.cstride, stream_ptr())
+            ora.add_grain_frame(want)
+            assert d.download().equal_all(want), (top, limit)
+        info = hip.last_launch_info()
+        one_pattern = "fgs_sei" not in name           # (the default SEI model: eight luma patterns, one chroma pattern)
+        assert info["one_c"] == (top <= limit) and info["one_y"] == (one_pattern and top <= limit), (top, limit, info["kernel"])
+        assert hip.seed_state() == ora.seed_state()

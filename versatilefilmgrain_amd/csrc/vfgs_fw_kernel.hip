@@ -334,6 +334,7 @@ struct PatchArgs {
 	uint32_t mask_luma, mask_chroma;
 	ImageLayout L;
 	int one_y, one_c, slot_y, slot_cb, slot_cr;
+	int pk16;             // 8 bit: one-pattern banks hold int16 values (vfgs_layout.h "packed 16-bit form")
 };
 
 __global__ __launch_bounds__(256) void fw_patch_tables(const PatchArgs p)
@@ -349,8 +350,16 @@ __global__ __launch_bounds__(256) void fw_patch_tables(const PatchArgs p)
 			if (p.slot_y < kSlots && (p.mask_luma >> p.slot_y & 1))
 			{
 				const int v = p.bank[(size_t)p.slot_y * 4096 + o];       // (generated values are clipped to +-127)
-				dst[r * L.y_rs + x] = (uint8_t)v;
-				dst[L.y_neg + r * L.y_rs + x] = (uint8_t)-v;
+				if (p.pk16)
+				{
+					*(int16_t*)(dst + r * L.y_rs + 2 * x) = (int16_t)v;
+					*(int16_t*)(dst + L.y_neg + r * L.y_rs + 2 * x) = (int16_t)-v;
+				}
+				else
+				{
+					dst[r * L.y_rs + x] = (uint8_t)v;
+					dst[L.y_neg + r * L.y_rs + x] = (uint8_t)-v;
+				}
 			}
 		}
 		else
@@ -370,8 +379,16 @@ __global__ __launch_bounds__(256) void fw_patch_tables(const PatchArgs p)
 				if (k < kSlots && (p.mask_chroma >> k & 1))
 				{
 					const int v = p.bank[(size_t)(kSlots + k) * 4096 + r * 64 + x];
-					p.img[L.c_off[c] + L.c_bank + r * L.c_rs + x] = (uint8_t)v;
-					p.img[L.c_off[c] + L.c_bank + L.c_neg + r * L.c_rs + x] = (uint8_t)-v;
+					if (p.pk16)
+					{
+						*(int16_t*)(p.img + L.c_off[c] + L.c_bank + r * L.c_rs + 2 * x) = (int16_t)v;
+						*(int16_t*)(p.img + L.c_off[c] + L.c_bank + L.c_neg + r * L.c_rs + 2 * x) = (int16_t)-v;
+					}
+					else
+					{
+						p.img[L.c_off[c] + L.c_bank + r * L.c_rs + x] = (uint8_t)v;
+						p.img[L.c_off[c] + L.c_bank + L.c_neg + r * L.c_rs + x] = (uint8_t)-v;
+					}
 				}
 			}
 		}
@@ -401,11 +418,12 @@ hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream)
 }
 
 hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby,
-                           bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, hipStream_t stream)
+                           bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, bool depth8, hipStream_t stream)
 {
 	PatchArgs p{};
 	p.img = img; p.bank = bank; p.mask_luma = mask_luma; p.mask_chroma = mask_chroma;
-	p.L = image_layout(csubx, csuby, one_y, one_c);
+	p.L = image_layout(csubx, csuby, one_y, one_c, depth8);
+	p.pk16 = depth8 && kPk16;
 	p.one_y = one_y; p.one_c = one_c; p.slot_y = slot_y; p.slot_cb = slot_cb; p.slot_cr = slot_cr;
 	const int n = 4096 + p.L.cw * p.L.ch;
 	hipLaunchKernelGGL(fw_patch_tables, dim3((n + 255) / 256), dim3(256), 0, stream, p);

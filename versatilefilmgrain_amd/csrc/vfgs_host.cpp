@@ -25,11 +25,11 @@
 
 namespace vfgs {
 hipError_t launch_grain(const KernelArgs& a, const FrameTable* list, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream);
-ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec);
+ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec, bool depth8);
 void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist);
 hipError_t launch_fw_generate(const FwLaunch& L, hipStream_t stream);
 hipError_t launch_fw_patch(uint8_t* img, const int8_t* bank, uint32_t mask_luma, uint32_t mask_chroma, int csubx, int csuby,
-                           bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, hipStream_t stream);
+                           bool one_y, bool one_c, int slot_y, int slot_cb, int slot_cr, bool depth8, hipStream_t stream);
 }
 
 // The constant tables of the grain models (oracle/dump_fw_tables.c documents origin and layout),
@@ -602,7 +602,7 @@ vfgs_hip_launch_info g_last_launch{};      // what the primary state's most rece
 bool g_last_launch_valid = false;
 // set while a host-memory entry point (the line call and its look-ahead stripes, vfgs_add_grain_stripe, vfgs_hip_add_grain_frames_host)
 // launches on the library's own staging buffers: vfgs_hip_last_launch_info().internal
-bool g_internal_launch = false;
+thread_local bool g_internal_launch = false;     // (per thread: the replicas' worker threads stage too; only the primary's run_device records launch info)
 struct InternalLaunch {
 	InternalLaunch() { g_internal_launch = true; }
 	~InternalLaunch() { g_internal_launch = false; }
@@ -773,6 +773,7 @@ int uniform_slot(const uint8_t (&plut)[256])
 void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool one_y, bool one_c, const int (&slot)[3])
 {
 	memset(img, 0, L.bytes);
+	const bool pk16 = s.bs == 0 && vfgs::kPk16;     // 8 bit: one-pattern components in the packed 16-bit form (vfgs_layout.h)
 	// banks
 	uint8_t* yb = img + L.y_off + L.y_bank;
 	for (int r = 0; r < 64; r++)
@@ -781,8 +782,17 @@ void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool
 			if (one_y)
 			{
 				const int v = slot[0] < vfgs::kSlots ? s.bank[0][slot[0]][r][x] : 0;
-				yb[r * L.y_rs + x] = (uint8_t)v;
-				yb[L.y_neg + r * L.y_rs + x] = (uint8_t)-v;      // the negated copy (never -128: one_pattern_ok)
+				if (pk16)
+				{
+					const int16_t p = (int16_t)v, n = (int16_t)-v;
+					memcpy(yb + r * L.y_rs + 2 * x, &p, 2);
+					memcpy(yb + L.y_neg + r * L.y_rs + 2 * x, &n, 2);
+				}
+				else
+				{
+					yb[r * L.y_rs + x] = (uint8_t)v;
+					yb[L.y_neg + r * L.y_rs + x] = (uint8_t)-v;      // the negated copy (never -128: image_form)
+				}
 			}
 			else
 				for (int k = 0; k < vfgs::kSlots; k++) yb[r * L.y_rs + x * vfgs::kSlots + k] = (uint8_t)s.bank[0][k][r][x];
@@ -796,8 +806,17 @@ void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool
 				if (one_c)
 				{
 					const int v = slot[1 + c] < vfgs::kSlots ? s.bank[1][slot[1 + c]][r][x] : 0;
-					cb[r * L.c_rs + x] = (uint8_t)v;
-					cb[L.c_neg + r * L.c_rs + x] = (uint8_t)-v;
+					if (pk16)
+					{
+						const int16_t p = (int16_t)v, n = (int16_t)-v;
+						memcpy(cb + r * L.c_rs + 2 * x, &p, 2);
+						memcpy(cb + L.c_neg + r * L.c_rs + 2 * x, &n, 2);
+					}
+					else
+					{
+						cb[r * L.c_rs + x] = (uint8_t)v;
+						cb[L.c_neg + r * L.c_rs + x] = (uint8_t)-v;
+					}
 				}
 				else
 					for (int k = 0; k < vfgs::kSlots; k++) cb[r * L.c_rs + x * vfgs::kSlots + k] = (uint8_t)s.bank[1][k][r][x];
@@ -807,6 +826,11 @@ void build_tables(const State& s, uint8_t* img, const vfgs::ImageLayout& L, bool
 	for (int c = 0; c < 3; c++)
 	{
 		uint32_t* lut = (uint32_t*)(c == 0 ? img + L.y_off : img + L.c_off[c - 1] + L.c_lut[c - 1]);
+		if (pk16 && (c == 0 ? one_y : one_c))
+		{
+			memcpy(lut, s.slut[c], 256);     // the scale bytes themselves (vfgs_hw.c:50); the shift travels in KernelArgs::pk_shift
+			continue;
+		}
 		for (int i = 0; i < 256; i++)
 		{
 			const int sl = s.plut[c][i] >> 4;   // vfgs_hw.c:212
@@ -862,8 +886,17 @@ void image_form(const State& s, bool wide, bool* one_y, bool* one_c)
 			if (memchr(s.bank[pt][k][r], 0x80, cols)) return false;
 		return true;
 	};
-	*one_y = !want_general && slot[0] >= 0 && negatable(0, slot[0]);
-	*one_c = !want_general && slot[1] >= 0 && slot[2] >= 0 && negatable(1, slot[1]) && negatable(1, slot[2]);
+	// 8 bit: the one-pattern form multiplies pattern and scale in 16 bits, two samples per instruction (vfgs_layout.h "packed 16-bit
+	// form"; vfgs_hw.c:263): |P| <= 127 (no -128, above), so the form is exact while max(scale) * 127 + 2^(shift-1) fits an int16
+	// -- scale <= 249 at the usual shift of 11; a LUT beyond that keeps the general form
+	auto fits16 = [&](int c) {
+		if (s.bs != 0 || !vfgs::kPk16) return true;
+		int mx = 0;
+		for (int i = 0; i < 256; i++) mx = std::max(mx, (int)s.slut[c][i]);
+		return mx * 127 + (1 << (s.scale_shift - 1)) <= 32767;
+	};
+	*one_y = !want_general && slot[0] >= 0 && negatable(0, slot[0]) && fits16(0);
+	*one_c = !want_general && slot[1] >= 0 && slot[2] >= 0 && negatable(1, slot[1]) && negatable(1, slot[2]) && fits16(1) && fits16(2);
 	if (wide && !(s.csubx == s.csuby && *one_c)) *one_y = *one_c = false;
 }
 
@@ -887,7 +920,7 @@ int upload_tables(State& s, hipStream_t stream, bool wide)
 	}
 	if (int e = fw_flush(s, stream)) return e;
 	void* dst = nullptr;
-	const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, one_y, one_c);
+	const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, one_y, one_c, s.bs == 0);
 	uint8_t* img = nullptr;
 	HIP_TRY(s.tables_ring.next(L.bytes, &dst, &img));
 	build_tables(s, img, L, one_y, one_c, slot);
@@ -897,7 +930,7 @@ int upload_tables(State& s, hipStream_t stream, bool wide)
 		// device-generated slots never visit the host: copy them bank -> image on the device
 		if (int e = fw_bank_stream(s, stream)) return e;
 		HIP_TRY(vfgs::launch_fw_patch((uint8_t*)dst, s.dev_bank, s.dev_origin[0], s.dev_origin[1], s.csubx, s.csuby, one_y, one_c,
-		                              slot[0], slot[1], slot[2], stream));
+		                              slot[0], slot[1], slot[2], s.bs == 0, stream));
 	}
 	HIP_TRY(s.tables_ring.uploaded(stream));
 	s.tables_dirty = false;
@@ -1011,6 +1044,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.listed = list ? 1 : 0;
 	a.lo2[0] = (uint32_t)(s.ymin << s.bs) * 0x10001u; a.hi2[0] = (uint32_t)(s.ymax << s.bs) * 0x10001u;
 	a.lo2[1] = (uint32_t)(s.cmin << s.bs) * 0x10001u; a.hi2[1] = (uint32_t)(s.cmax << s.bs) * 0x10001u;
+	a.pk_shift = s.scale_shift;     // (read by the 8-bit one-pattern forms only: vfgs_layout.h "packed 16-bit form"; 8..13, check_state)
 	// Geometry: a wave streams whole rows (positions = the row's units + the one behind them: the lanes compute bytes shifted
 	// by part of a unit); a workgroup = kWavesPerWG x rw_rpw rows of one block row, VFGS_RW_WG_BYTES where the block row allows.
 	// Launches that leave wave slots empty get workgroups of half the rows (single frames up to 2160p).
@@ -1150,7 +1184,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		li.parts_per_row = (int)nparts;
 		li.persistent_luma_workgroups = persist ? a.persist_wgs : 0;
 		li.waves_per_workgroup = vfgs::kWavesPerWG;
-		const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, s.img_one_y, s.img_one_c);
+		const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, s.img_one_y, s.img_one_c, s.bs == 0);
 		li.lds_bytes_per_workgroup = L.lds_bytes + vfgs::kParamBytes;
 		vfgs::describe_launch(li.kernel, sizeof li.kernel, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, persist);
 		g_last_launch_valid = true;
@@ -2190,7 +2224,7 @@ int vfgs_hip_add_grain_frame_part_dev(void* dY, void* dU, void* dV, unsigned wid
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
-	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	if (part_y > frame_height || part_height > frame_height - part_y) return fail(12, "part exceeds the frame");     // (no 32-bit wrap)
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, 1, 0, 0, pick_stream(stream));
 }
 
@@ -2213,7 +2247,7 @@ int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned wi
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
-	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	if (part_y > frame_height || part_height > frame_height - part_y) return fail(12, "part exceeds the frame");     // (no 32-bit wrap)
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(dY, dU, dV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
 	                  y_frame_pitch_bytes, c_frame_pitch_bytes, pick_stream(stream));
@@ -2222,9 +2256,9 @@ int vfgs_hip_add_grain_frames_part_dev(void* dY, void* dU, void* dV, unsigned wi
 // Frames anywhere in device memory (vfgs_hip.h): validated as a whole before anything moves, then launched in chunks of
 // kListFrames frames whose plane pointers travel in the kernel arguments.
 static int run_frame_list(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes, unsigned width, unsigned height,
-                          unsigned stride, unsigned cstride, hipStream_t stream, DstGeom dg, unsigned part_y = 0, unsigned part_h = ~0u)
+                          unsigned stride, unsigned cstride, hipStream_t stream, DstGeom dg, bool whole = true, unsigned part_y = 0, unsigned part_h = 0)
 {
-	if (part_h == ~0u) part_h = height;
+	if (whole) { part_y = 0; part_h = height; }
 	State& s = S();
 	if (int e = ensure_init(-1)) return e;
 	if (nframes == 0) return 0;
@@ -2235,12 +2269,45 @@ static int run_frame_list(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_p
 		if (int e = check_geometry(s, src[f].Y, src[f].U, src[f].V, width, stride, cstride)) return e;
 		if ((((uintptr_t)dst[f].Y | (uintptr_t)dst[f].U | (uintptr_t)dst[f].V) & 15)) return fail(7, "plane pointers must be 16-byte aligned");
 	}
-	// the frames run concurrently: a destination that appears twice would be a race where consecutive calls are not
-	std::vector<const void*> seen;
-	seen.reserve(3 * (size_t)nframes);
-	for (unsigned f = 0; f < nframes; f++) { seen.push_back(dst[f].Y); seen.push_back(dst[f].U); seen.push_back(dst[f].V); }
-	std::sort(seen.begin(), seen.end());
-	if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return fail(18, "frame list: a destination plane is listed twice");
+	// The frames run concurrently: destination planes that overlap (the same plane listed twice, or two that share bytes) would be
+	// a race where consecutive calls are not, and so would a source plane of one frame that shares bytes with the destination of
+	// ANOTHER (that frame may already have been grained when it is read).  The bytes of a plane: its rows of the stripe, whole
+	// 16-sample blocks each (check_geometry).  A frame's own source and destination are either the same plane (in place) or disjoint.
+	{
+		const uint64_t sz = s.bs ? 2 : 1, nblk = (width + 15) / 16;
+		const uint64_t crows = part_h ? (uint64_t)(part_y + part_h - 1) / s.csuby - part_y / s.csuby + 1 : 0;
+		const uint64_t dsz = dg.out8 ? 1 : sz, dstr = dg.out8 ? dg.stride : stride, dcstr = dg.out8 ? dg.cstride : cstride;
+		auto extent = [&](uint64_t rows, uint64_t pitch, uint64_t rowb) { return rows ? (rows - 1) * pitch + rowb : 0; };
+		const uint64_t ext_s[3] = {extent(part_h, stride * sz, nblk * 16 * sz), extent(crows, cstride * sz, nblk * 16 / s.csubx * sz), 0};
+		const uint64_t ext_d[3] = {extent(part_h, dstr * dsz, nblk * 16 * dsz), extent(crows, dcstr * dsz, nblk * 16 / s.csubx * dsz), 0};
+		struct Span { uintptr_t lo, hi; unsigned frame; };
+		std::vector<Span> d;
+		d.reserve(3 * (size_t)nframes);
+		for (unsigned f = 0; f < nframes; f++)
+		{
+			const void* pl[3] = {dst[f].Y, dst[f].U, dst[f].V};
+			for (int c = 0; c < 3; c++) d.push_back({(uintptr_t)pl[c], (uintptr_t)pl[c] + ext_d[c ? 1 : 0], f});
+		}
+		std::sort(d.begin(), d.end(), [](const Span& a, const Span& b) { return a.lo < b.lo; });
+		for (size_t i = 1; i < d.size(); i++)
+			if (d[i].lo < d[i - 1].hi || d[i].lo == d[i - 1].lo)
+				return fail(18, d[i].lo == d[i - 1].lo ? "frame list: a destination plane is listed twice" : "frame list: destination planes of frames %u and %u overlap",
+				            d[i - 1].frame, d[i].frame);
+		for (unsigned f = 0; f < nframes && src != dst; f++)
+		{
+			const void* pl[3] = {src[f].Y, src[f].U, src[f].V};
+			const void* own[3] = {dst[f].Y, dst[f].U, dst[f].V};
+			for (int c = 0; c < 3; c++)
+			{
+				const uintptr_t lo = (uintptr_t)pl[c], hi = lo + ext_s[c ? 1 : 0];
+				// destinations are disjoint and sorted: the first one that ends behind lo is the only candidate below hi ... and its successors
+				auto it = std::upper_bound(d.begin(), d.end(), lo, [](uintptr_t v, const Span& x) { return v < x.hi; });
+				for (; it != d.end() && it->lo < hi; ++it)
+					if (!(it->frame == f && pl[c] == own[c] && it->lo == lo))
+						return fail(18, "frame list: a source plane of frame %u shares bytes with a destination plane of frame %u", f, it->frame);
+			}
+		}
+	}
 	for (unsigned f0 = 0; f0 < nframes; f0 += vfgs::kListFrames)
 	{
 		const unsigned n = std::min<unsigned>(vfgs::kListFrames, nframes - f0);
@@ -2272,8 +2339,8 @@ int vfgs_hip_add_grain_frame_list_part_dev(const vfgs_hip_frame_ptrs* frames, un
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
-	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
-	return run_frame_list(frames, frames, nframes, width, frame_height, stride, cstride, pick_stream(stream), DstGeom(), part_y, part_height);
+	if (part_y > frame_height || part_height > frame_height - part_y) return fail(12, "part exceeds the frame");     // (no 32-bit wrap)
+	return run_frame_list(frames, frames, nframes, width, frame_height, stride, cstride, pick_stream(stream), DstGeom(), false, part_y, part_height);
 }
 
 int vfgs_hip_add_grain_frame_list_copy_dev(const vfgs_hip_frame_ptrs* src, const vfgs_hip_frame_ptrs* dst, unsigned nframes, unsigned width,
@@ -2328,7 +2395,7 @@ int vfgs_hip_add_grain_copy_dev(const void* sY, const void* sU, const void* sV, 
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
-	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	if (part_y > frame_height || part_height > frame_height - part_y) return fail(12, "part exceeds the frame");     // (no 32-bit wrap)
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	return run_device(sY, sU, sV, dY, dU, dV, width, 0, frame_height, part_y, part_height, stride, cstride, nframes,
 	                  y_frame_pitch_bytes, c_frame_pitch_bytes, pick_stream(stream));
@@ -2343,7 +2410,7 @@ int vfgs_hip_add_grain_copy8_dev(const void* sY, const void* sU, const void* sV,
 	std::lock_guard<std::mutex> g(g_mu);
 	S().gen++;
 	if (part_y & 15) return fail(11, "part_y must be a multiple of 16");
-	if (part_y + part_height > frame_height) return fail(12, "part exceeds the frame");
+	if (part_y > frame_height || part_height > frame_height - part_y) return fail(12, "part exceeds the frame");     // (no 32-bit wrap)
 	if ((y_frame_pitch_bytes | c_frame_pitch_bytes) & 15) return fail(13, "frame pitches must be multiples of 16 bytes");
 	DstGeom dg;
 	dg.out8 = true;

@@ -91,6 +91,42 @@ __device__ __forceinline__ int mul_byte_i24(const int b, uint32_t d, uint32_t y)
 	return r;
 }
 
+// ---- packed 16-bit helpers (8-bit one-pattern form, vfgs_layout.h "packed 16-bit form") ----
+// two samples per instruction: {a.lo * b.lo + c.lo, a.hi * b.hi + c.hi} in 16 bits (the host has proven that nothing overflows)
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t r;
+	asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+	return r;
+}
+// both halves shifted right arithmetically by the corresponding half of `sh`
+__device__ __forceinline__ uint32_t pk_ashr_i16(uint32_t sh, uint32_t v)
+{
+	uint32_t r;
+	asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(r) : "s"(sh), "v"(v));
+	return r;
+}
+// x.i16 * (HI ? y.hi : y.lo).i16 + c in 32 bits: a block edge's filtered value times its sample's scale, which sits in one half
+// of the pair's register
+template <bool HI>
+__device__ __forceinline__ int mad_i32_i16(int x, uint32_t y, int c)
+{
+	int r;
+	if (HI) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(r) : "v"(x), "v"(y), "s"(c));
+	else asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(c));
+	return r;
+}
+__device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)      // mask ? a : b, bit by bit
+{
+	uint32_t r;
+	asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+	return r;
+}
+
 __device__ __forceinline__ int swap_lane_pairs(int v)
 {
 	// quad_perm:[1,0,3,2]: lane 2m <-> lane 2m+1
@@ -150,7 +186,7 @@ struct RunParam {
 // vfgs_hw.c:99-138 with the component as wave-uniform data: the x field is 10 bits at `sx`, the
 // y field the low 10 bits of the register rotated right by `sy` (component 1 takes bits 31:24
 // and 1:0 -- exactly a rotation by 24), the sign bit at `sb`.  Returns the LDS address; sign in *neg.
-template <int SUBX, int SUBY, int RS, bool ONE>
+template <int SUBX, int SUBY, int RS, int SB>
 __device__ __forceinline__ uint32_t block_param(uint32_t v, uint32_t bank_off, int sx, int sy, int sb, bool* neg)
 {
 	const uint32_t fx = (v >> sx) & 0x3ff;
@@ -158,7 +194,7 @@ __device__ __forceinline__ uint32_t block_param(uint32_t v, uint32_t bank_off, i
 	const uint32_t ox = (__umul24(fx, 13u) >> 10) * (4 / SUBX);
 	const uint32_t oy = (__umul24(fy, 12u) >> 10) * (4 / SUBY);
 	*neg = (v >> sb) & 1;
-	return __umul24(oy, (uint32_t)RS) + ox * (ONE ? 1 : kSlots) + bank_off;     // bytes per sample position: 1 or one per slot
+	return __umul24(oy, (uint32_t)RS) + ox * SB + bank_off;     // SB = bytes per sample position: 1 (8-bit one-pattern form: 2) or one per slot
 }
 
 // ---------------------------------------------------------------------------------------
@@ -185,11 +221,14 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
                                             const RunParam<LaneMap<DEPTH == 8 ? 16 : 8, BW>::NR>& up,
                                             const uint32_t lutb, const uint32_t rowoff, const uint32_t uprowoff, const int wcur, const int wup,
                                             const bool (&edge_on)[LaneMap<DEPTH == 8 ? 16 : 8, BW>::PAIR ? 1 : LaneMap<DEPTH == 8 ? 16 : 8, BW>::NE],
-                                            const bool first, const uint32_t lo2, const uint32_t hi2)
+                                            const bool first, const uint32_t lo2, const uint32_t hi2, const int pkshift)
 {
 	constexpr int NS = DEPTH == 8 ? 16 : 8;
 	using M = LaneMap<NS, BW>;
 	constexpr int NR = M::NR, NQ = M::NQ;
+	// 8-bit one-pattern form: int16 bank + table of scale bytes (vfgs_layout.h "packed 16-bit form"); pkshift = the scale shift
+	constexpr bool PK = DEPTH == 8 && ONE && kPk16;
+	static_assert(!(PK && M::PAIR), "lane pairs are 10-bit lanes");
 	// unpack the block parameters
 	int sg[NR];              // 0 / -1: the block's sign is negative
 	uint32_t ad[NR], k2s[NR];
@@ -201,6 +240,63 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 		// points into the negated bank (vfgs_layout.h); the overlap lines blend true values by signed weights: back to the bank
 		ad[r] = (rp.pa[r] & 0xffffu) + rowoff - ((ONE && OVERLAP) ? ((uint32_t)sg[r] & (uint32_t)NEG) : 0u);
 		k2s[r] = ONE ? 0u : (OVERLAP ? lutb : (((uint32_t)sg[r] & 0x04000400u) | lutb));     // OVERLAP: the +scale table
+	}
+	if constexpr (PK && !OVERLAP)
+	{
+		// ---- two samples per instruction (every line but the two overlap lines of a block row) ----
+		const uint32_t rnd = 1u << (pkshift - 1);
+		const uint32_t rpk = rnd * 0x10001u, shpk = (uint32_t)pkshift * 0x10001u;
+		const uint8_t* lut = lds + (lutb & 0xffffu);
+		uint32_t S[NS / 2], Pp[NS / 2], G[NS / 2];
+		// scale gather (vfgs_hw.c:211,239): the sample IS the address; a pair's scales in the two halves of one register
+#pragma unroll
+		for (int q = 0; q < NQ; q++)
+		{
+			const uint32_t v = w[q];
+			const uint32_t s0 = lut[v & 0xffu], s1 = lut[(v >> 8) & 0xffu], s2 = lut[(v >> 16) & 0xffu], s3 = lut[v >> 24];
+			S[2 * q] = s0 | (s1 << 16);
+			S[2 * q + 1] = s2 | (s3 << 16);
+		}
+		// pattern fetch: four int16 = one 8-byte read (two dwords where the block offsets are multiples of 2 samples, ALIGN2)
+#pragma unroll
+		for (int q = 0; q < NQ; q++)
+		{
+			uint32_t a8 = ad[M::run(q)] + M::col(q) * 2;
+#ifdef VFGS_PK_NO_READ2      // developer A/B: keep the compiler from pairing two quads' 8-byte reads into one ds_read2_b64 (8 LDS cycles where two ds_read_b64 take 2 each)
+			if (!ALIGN2 && (q & 1)) asm volatile("" : "+v"(a8));
+#endif
+			if (ALIGN2) { Pp[2 * q] = *(const uint32_t*)(lds + a8); Pp[2 * q + 1] = *(const uint32_t*)(lds + a8 + 4); }
+			else { const u32x2 t = *(const u32x2*)(lds + a8); Pp[2 * q] = t.x; Pp[2 * q + 1] = t.y; }
+		}
+		// round(scale * P, shift) (vfgs_hw.c:263) for both samples of a pair
+#pragma unroll
+		for (int m = 0; m < NS / 2; m++) G[m] = pk_ashr_i16(shpk, pk_mad_i16(Pp[m], S[m], rpk));
+		// the two samples at a block edge (vfgs_hw.c:250-259): 3-tap filter on the unfiltered neighbours as dot products of the
+		// packed pairs, 32-bit product with the sample's scale (the filtered value may reach +-159), result dropped into its half
+#pragma unroll
+		for (int ed = 0; ed < M::NE; ed++)
+		{
+			const int s = 4 * M::edge_quad(ed), pa = s / 2 + 1, pb = s / 2 + 2;      // pairs (l1, l0) | (r0, r1)
+			const uint32_t A = Pp[pa], B = Pp[pb];
+			const int fl = dot2_i16(B, 0x00000001u, dot2_i16(A, 0x00030001u, 2)) >> 2;     // (l1 + 3 l0 + r0 + 2) >> 2
+			const int fr = dot2_i16(A, 0x00010000u, dot2_i16(B, 0x00010003u, 2)) >> 2;     // (l0 + 3 r0 + r1 + 2) >> 2
+			const int gl = mad_i32_i16<true>(fl, S[pa], (int)rnd), gr = mad_i32_i16<false>(fr, S[pb], (int)rnd);
+			const uint32_t mA = edge_on[ed] ? 0xffff0000u : 0u, mB = mA >> 16;
+			G[pa] = bfi(mA, (uint32_t)gl << (16 - pkshift), G[pa]);
+			G[pb] = bfi(mB, (uint32_t)(gr >> pkshift), G[pb]);
+		}
+		// add, clip (vfgs_hw.c:264-267), two samples per instruction
+#pragma unroll
+		for (int d = 0; d < 4; d++)
+		{
+			const uint32_t v01 = __builtin_amdgcn_perm(0, w[d], 0x0c010c00), v23 = __builtin_amdgcn_perm(0, w[d], 0x0c030c02);
+			s16x2 a = __builtin_bit_cast(s16x2, v01) + __builtin_bit_cast(s16x2, G[2 * d]);
+			s16x2 b = __builtin_bit_cast(s16x2, v23) + __builtin_bit_cast(s16x2, G[2 * d + 1]);
+			a = __builtin_elementwise_min(__builtin_elementwise_max(a, __builtin_bit_cast(s16x2, lo2)), __builtin_bit_cast(s16x2, hi2));
+			b = __builtin_elementwise_min(__builtin_elementwise_max(b, __builtin_bit_cast(s16x2, lo2)), __builtin_bit_cast(s16x2, hi2));
+			w[d] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x06040200);
+		}
+		return;
 	}
 	uint32_t e[NS];
 	int P[NS];
@@ -221,6 +317,16 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 				e[4 * q + 2 * h + 1] = *(const uint32_t*)(lds + (idx >> 16));
 			}
 		}
+		else if (PK)
+		{
+			// (overlap lines of the packed 16-bit form: the scale byte itself)
+			const uint32_t v = w[q];
+			const uint8_t* lut = lds + (lutb & 0xffffu);
+			e[4 * q + 0] = lut[v & 0xffu];
+			e[4 * q + 1] = lut[(v >> 8) & 0xffu];
+			e[4 * q + 2] = lut[(v >> 16) & 0xffu];
+			e[4 * q + 3] = lut[v >> 24];
+		}
 		else
 		{
 			const uint32_t v = w[q], k1 = k2 & 0xffffu;
@@ -235,7 +341,17 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	// One-pattern form: 4 samples = one dword (at a 2-byte aligned address where the block offsets are multiples of 2
 	// samples, ALIGN2: cut out of two aligned dwords), each value sign-extended out of its byte.
 	auto fetch4 = [&](uint32_t adq, int q, int (&out)[4], uint32_t& raw) {
-		if (ONE)
+		if (PK)
+		{
+			const uint32_t a8 = adq + M::col(q) * 2;
+			uint32_t p01, p23;
+			if (ALIGN2) { p01 = *(const uint32_t*)(lds + a8); p23 = *(const uint32_t*)(lds + a8 + 4); }
+			else { const u32x2 t = *(const u32x2*)(lds + a8); p01 = t.x; p23 = t.y; }
+			raw = p01;
+			out[0] = (int)(p01 << 16) >> 16; out[1] = (int)p01 >> 16;
+			out[2] = (int)(p23 << 16) >> 16; out[3] = (int)p23 >> 16;
+		}
+		else if (ONE)
 		{
 			uint32_t d;
 			if (ALIGN2)
@@ -348,7 +464,8 @@ __device__ __forceinline__ void grain_unit(const uint8_t* lds, uint32_t (&w)[4],
 	{
 		// (8 bit only: +1..2 % there, 8 VGPRs fewer and no spill left in the all-one-pattern kernels; at 10 bit the same change
 		// lets the compiler reach six waves per SIMD, which these kernels do not like: -1..-2.5 %, profiles/r04_ab5_sdwa_multiply.log)
-		if (DEPTH == 8 && ONE && !OVERLAP && !edge_sample(i)) G[i] = mul_byte_i24(i % 4, pdw[i / 4], e[i]) + 0x8000;
+		if (PK) G[i] = mad_i24(P[i], e[i], 1 << (pkshift - 1)) << (16 - pkshift);     // (overlap lines only; < 2^24: |P| <= 199, scale <= 255)
+		else if (DEPTH == 8 && ONE && !OVERLAP && !edge_sample(i)) G[i] = mul_byte_i24(i % 4, pdw[i / 4], e[i]) + 0x8000;
 		else G[i] = mad_i24(P[i], e[i], 0x8000);
 	}
 	auto clip2 = [&](uint32_t v, int g0, int g1) {
@@ -450,6 +567,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 {
 	constexpr int NS = DEPTH == 8 ? 16 : 8;
 	constexpr int SZ = DEPTH > 8 ? 2 : 1;
+	constexpr int SB = ONE ? ((DEPTH == 8 && kPk16) ? 2 : 1) : kSlots;     // bytes of a bank per sample position (vfgs_layout.h)
 	using M = LaneMap<NS, BW>;
 	constexpr int NR = M::NR;
 	constexpr int RPB = 16 / SUBY;                       // rows of this plane per block row
@@ -544,9 +662,9 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 			const uint32_t blk = (uint32_t)min(max(B0 + e - 1, 0), last);
 			bool neg;
 			const uint32_t vc = __builtin_amdgcn_alignbit(wc[i].y, wc[i].x, (cur_bit + blk) & 31);
-			const uint32_t pc = (block_param<SUBX, SUBY, RS, ONE>(vc, bank_off, fsx, fsy, fsb, &neg) + ((ONE && neg) ? (uint32_t)NEG : 0u)) | (neg ? 0x80000000u : 0u);
+			const uint32_t pc = (block_param<SUBX, SUBY, RS, SB>(vc, bank_off, fsx, fsy, fsb, &neg) + ((ONE && neg) ? (uint32_t)NEG : 0u)) | (neg ? 0x80000000u : 0u);
 			const uint32_t vu = __builtin_amdgcn_alignbit(wu[i].y, wu[i].x, (up_bit + blk) & 31);
-			const uint32_t pu = block_param<SUBX, SUBY, RS, ONE>(vu, bank_off, fsx, fsy, fsb, &neg) | (neg ? 0x80000000u : 0u);
+			const uint32_t pu = block_param<SUBX, SUBY, RS, SB>(vu, bank_off, fsx, fsy, fsb, &neg) | (neg ? 0x80000000u : 0u);
 			if (e < kParamEntries)
 			{
 				*(uint32_t*)(lds + PT_CUR + e * 4) = pc;
@@ -618,7 +736,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 	const uint32_t lutb = lut_off * 0x10001u;
 	const uint32_t lo2 = a.lo2[pt], hi2 = a.hi2[pt];
 	const bool first = M::PAIR && (lane & 1);                              // PAIR: odd lane positions hold the first half of a block
-	const uint32_t pairoff = M::PAIR ? (first ? 0u : 8u * (ONE ? 1 : kSlots)) : 0u;
+	const uint32_t pairoff = M::PAIR ? (first ? 0u : 8u * SB) : 0u;
 	const uint32_t idx0 = (M::PAIR ? (uint32_t)(lane + 1) >> 1 : (uint32_t)lane * LPB) * 4;   // byte offset of my first entry in position 0 of a part
 	const int cl = M::PAIR ? lane - 1 - (lane & 1) : lane * LPB - 1;       // PAIR: left unit of my lane pair; else: block of run 0 (both for position 0)
 	constexpr int SSTEP = M::PAIR ? 64 : BPS;                              // what `cl` advances by per position
@@ -703,13 +821,13 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 					{
 #pragma unroll
 						for (int rr = 0; rr < NR; rr++) up.pa[rr] = *(const uint32_t*)(pe + PT_UP + (p * BPS + rr) * 4) + pairoff;
-						grain_unit<DEPTH, BW, true, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, wc_, wu_, edge_on, first, lo2, hi2);
+						grain_unit<DEPTH, BW, true, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, wc_, wu_, edge_on, first, lo2, hi2, a.pk_shift);
 					}
 					else
 					{
 #pragma unroll
 						for (int rr = 0; rr < NR; rr++) up.pa[rr] = 0u;
-						grain_unit<DEPTH, BW, false, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, 0, 0, edge_on, first, lo2, hi2);
+						grain_unit<DEPTH, BW, false, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, 0, 0, edge_on, first, lo2, hi2, a.pk_shift);
 					}
 				}
 				uint32_t o[DW];
@@ -787,7 +905,7 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 					for (int rr = 0; rr < NR; rr++) rp.pa[rr] = *(const uint32_t*)(pe + PT_CUR + (u * BPS + rr) * 4) + pairoff;
 #pragma unroll
 					for (int rr = 0; rr < NR; rr++) up.pa[rr] = OV ? *(const uint32_t*)(pe + PT_UP + (u * BPS + rr) * 4) + pairoff : 0u;
-					grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, OV ? wc_ : 0, OV ? wu_ : 0, edge_on, first, lo2, hi2);
+					grain_unit<DEPTH, BW, OV, ONE, ONE && SUBX == 2, NEG>(lds, t, rp, up, lutb, rowoff, uprowoff, OV ? wc_ : 0, OV ? wu_ : 0, edge_on, first, lo2, hi2, a.pk_shift);
 				}
 				uint32_t o[DW];
 				results(t, o);
@@ -855,14 +973,17 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 // allocation granule above the 96 of five waves: asking for five costs one register spilled in the prologue and reloaded
 // once per row (not in the group loop) and is worth 3 % (profiles/r03_ab22_lds_probes_and_occupancy.log); the general-form
 // kernels are held at four by their LDS image, the others by spills.
+#ifndef VFGS_PK_WAVES
+#define VFGS_PK_WAVES 5
+#endif
 template <int DEPTH, bool ONEY, bool ONEC, bool WIDE>
-constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && !WIDE && VFGS_WG_PER_CU == 4) ? 5 : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
+constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && !WIDE && VFGS_WG_PER_CU == 4) ? VFGS_PK_WAVES : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
 
 // in place or out of place; workgroups numbered frame -> plane -> block row -> part of the block row
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>
 __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC, WIDE>())) void grain_rw_kernel(const KernelArgs a, const FrameTable ft)
 {
-	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC);
+	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC, DEPTH == 8);
 	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes + kParamBytes];
 
 	const int lane = threadIdx.x & 63;
@@ -982,6 +1103,6 @@ void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool 
 	snprintf(out, n, "grain_rw_kernel<%d,%d,%d,%s,%s,%s,%s,%s>", depth, csubx, csuby, b(out8), b(oney), b(onec), b(wide), b(persist));
 }
 
-ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec) { return image_layout(csubx, csuby, oney, onec); }
+ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec, bool depth8) { return image_layout(csubx, csuby, oney, onec, depth8); }
 
 }  // namespace vfgs

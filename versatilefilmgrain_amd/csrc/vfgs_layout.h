@@ -38,12 +38,17 @@ constexpr int kBlock = 16;       // luma samples per grain block
 // developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
 #if !defined(VFGS_DEV_BUILD)
 #if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
-    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS) || defined(VFGS_PERSIST_MAX_WG_KB)
+    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_NO_PK16) || defined(VFGS_PK_NO_READ2) || defined(VFGS_PK_WAVES) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS) || defined(VFGS_PERSIST_MAX_WG_KB)
 #error "libvfgs_hip: a tuning knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
 #endif
 
 constexpr int kWavesPerWG = VFGS_WAVES;
+#ifdef VFGS_NO_PK16               // developer builds only: the 8-bit one-pattern components keep round 5's byte bank + dword LUT (same-box A/Bs)
+constexpr bool kPk16 = false;
+#else
+constexpr bool kPk16 = true;      // 8-bit one-pattern components use the packed 16-bit form (below)
+#endif
 
 // The kernels (vfgs_kernel.hip "Row walk"): a wave streams whole rows, the workgroup's block parameters live in LDS
 // behind the table image: two tables (this block row's registers, the block row above's) of one dword per grain block +
@@ -77,6 +82,14 @@ constexpr int kParamBytes = 2 * kParamTableBytes;
 // only chooses this form for patterns without the value -128, which has no negation in a byte (the firmware's generators
 // clip to +-127, vfgs_fw.c:321-323,494).
 //
+// ONE-PATTERN form at 8 BIT ("packed 16-bit form", round 6): the bank holds the pattern as int16 values (rows of 2 x columns + 16
+// bytes, followed by the negated copy) and the LUT is the plain table of the 256 scale BYTES (vfgs_hw.c:50).  Two samples then
+// share every vector instruction behind the gathers: a pair's pattern values arrive packed out of LDS (four samples = one
+// ds_read_b64), v_pk_mad_i16 (pattern x scale + 2^(shift-1)), v_pk_ashrrev_i16, and the packed add / max / min of the clip --
+// exact because |P| <= 127 and the host only chooses the form when max(scale) * 127 + 2^(shift-1) <= 32767 (image_form in
+// vfgs_host.cpp; otherwise the general form serves the component).  The two samples at a block edge (after the 3-tap filter
+// up to +-159) and the two overlap lines of a block row (after the blend up to +-199) keep 32-bit products.
+//
 // LUT (one dword per 8-bit intensity; per component TWO tables of 256 entries, the first with
 // +scale, the second with -scale, so that a block's random sign is applied by choosing the table
 // instead of multiplying every sample).  A component's pair of tables starts at a multiple of
@@ -98,17 +111,20 @@ struct ImageLayout {
 	int cw, ch;                 // chroma bank columns actually addressable, rows
 };
 
-constexpr ImageLayout image_layout(int csubx, int csuby, bool one_y, bool one_c)
+constexpr ImageLayout image_layout(int csubx, int csuby, bool one_y, bool one_c, bool depth8)
 {
 	ImageLayout L{};
 	L.lut_bytes = 2 * 256 * 4;
 	L.cw = 64 / csubx;
 	L.ch = 64 / csuby;
-	L.y_rs = one_y ? 64 + 16 : 64 * kSlots + 16;
-	L.c_rs = one_c ? L.cw + 16 : L.cw * kSlots + 16;
-	// (the one-pattern form never reads the -scale table: its sign is a choice of bank; only the +scale half is stored)
-	L.y_bank = one_y ? L.lut_bytes / 2 : L.lut_bytes;
-	L.c_bank = one_c ? L.lut_bytes / 2 : L.lut_bytes;
+	depth8 = depth8 && kPk16;
+	const int ob = depth8 ? 2 : 1;     // bytes per sample of a one-pattern bank (8 bit: the packed 16-bit form)
+	L.y_rs = one_y ? 64 * ob + 16 : 64 * kSlots + 16;
+	L.c_rs = one_c ? L.cw * ob + 16 : L.cw * kSlots + 16;
+	// (the one-pattern form never reads the -scale table: its sign is a choice of bank; only the +scale half is stored -- at 8 bit
+	// as the 256 scale bytes)
+	L.y_bank = one_y ? (depth8 ? 256 : L.lut_bytes / 2) : L.lut_bytes;
+	L.c_bank = one_c ? (depth8 ? 256 : L.lut_bytes / 2) : L.lut_bytes;
 	L.y_neg = one_y ? 64 * L.y_rs : 0;
 	L.c_neg = one_c ? L.ch * L.c_rs : 0;
 	L.y_bytes = L.y_bank + 64 * L.y_rs + L.y_neg;
@@ -171,6 +187,7 @@ struct KernelArgs {
 	int lfronts;              // log2 of the frames of a batch that are swept at the same time (their workgroups are dealt out in turn)
 	int persist_wgs;          // PERSIST kernels: P luma workgroups share the launch's nframes x pd[0].wgs luma tasks (task t -> workgroup t % P) ...
 	int persist_step_f, persist_step_r;   // ... and P = persist_step_f * pd[0].wgs + persist_step_r: what a workgroup advances by
+	int pk_shift;             // 8-bit one-pattern forms (packed 16-bit form, above): the scale shift of vfgs_hw.c:263, 8..13
 	uint32_t lo2[2], hi2[2];  // clip bounds in sample units (I_min<<bs ...) in both halves of a dword, per plane type (vfgs_hw.c:264-267)
 };
 
