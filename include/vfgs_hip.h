@@ -76,7 +76,9 @@ void vfgs_add_grain_line(void* Y, void* U, void* V, int y, int width);
  * line of the first frame on; it stays valid for walks that start at these pointers; all-NULL revokes it.
  * For a binary that cannot be rebuilt, the environment variable VFGS_HIP_FRAME_HEIGHT=<lines> makes the same promise for
  * every walk that starts at line 0 (planes of at least that many lines at the pitches the first lines show): the first
- * frame then costs three line round trips instead of one per line (4320p: 0.36 s -> 12 ms). */
+ * frame then costs three line round trips instead of one per line (4320p: 0.36 s -> 12 ms inside the library; a short run of
+ * the unchanged CLI, promised and plain runs interleaved on one box: never slower, 0.1 s faster at 4320p x 3 frames --
+ * profiles/r06_cli_short_runs.log; round 5's "slower with the promise" was the order of its runs). */
 void vfgs_hip_line_lookahead(int enable);
 int vfgs_hip_declare_frame(const void* Y, const void* U, const void* V, unsigned width, unsigned height,
                            unsigned stride, unsigned cstride);
@@ -192,6 +194,18 @@ void vfgs_hip_get_params(int out[8]);
  * stream lives in device memory): out[4] = { windows uploaded in a caller's stream (a bubble between two of its kernels), windows
  * built ahead on the library's copy stream, switches to a window built ahead, 32-bit words of the current window }. */
 void vfgs_hip_get_stream_stats(uint64_t out[4]);
+/* A batch of stripes (vfgs_hip_add_grain_frames_part_dev, vfgs_hip_add_grain_frame_list_part_dev: what one rank of a stripe split runs
+ * per step) that covers at most about two thirds of its frames reads short runs of that stream, a whole frame's steps apart
+ * (vfgs_hw.c:291-298,309-310: (ceil(height / 16) - 1) x ceil(width / 16) steps per frame).  The library builds those runs alone, each
+ * from the one before by a jump -- the step of vfgs_hw.c:74-79 is linear over GF(2), n steps are one 32 x 32 bit matrix -- and
+ * uploads the NEXT call's runs while this call's kernel works: out[4] = { images built in a caller's stream, images built ahead on
+ * the copy stream, switches to an image built ahead, 1 if the most recent launch read such an image }.  The environment variable
+ * VFGS_HIP_STRIPE_JUMP=0 keeps the contiguous window for those calls too (results are the same either way). */
+void vfgs_hip_get_stripe_stream_stats(uint64_t out[4]);
+/* The generator behind it, host only (no GPU needed): out[f * seg_words + k], f < nseg, k < seg_words = the 32-bit register
+ * (vfgs_hw.c:74-79) after first_bit + f * step_bits + 32 * k steps from `reg` -- what `prng` would return after stepping
+ * that far, without the stepping.  0 or an error code. */
+int vfgs_hip_lfsr_segments(unsigned int reg, uint64_t first_bit, uint64_t step_bits, unsigned nseg, unsigned seg_words, uint32_t* out);
 
 /* Last error of a vfgs_hip_* call (0 = none) and its text. */
 int vfgs_hip_last_error(void);

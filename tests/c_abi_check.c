@@ -19,7 +19,7 @@ int main(void)
 		(void (*)(void))vfgs_hip_add_grain_copy8_dev, (void (*)(void))vfgs_hip_add_grain_frame_list_dev, (void (*)(void))vfgs_hip_add_grain_frame_list_part_dev, (void (*)(void))vfgs_hip_add_grain_frame_list_copy_dev,
 		(void (*)(void))vfgs_hip_add_grain_frame_list_copy8_dev, (void (*)(void))vfgs_hip_get_seed_state, (void (*)(void))vfgs_hip_get_luts, (void (*)(void))vfgs_hip_get_params, (void (*)(void))vfgs_hip_last_error,
 		(void (*)(void))vfgs_hip_last_error_string, (void (*)(void))vfgs_hip_timer_begin, (void (*)(void))vfgs_hip_timer_end, (void (*)(void))vfgs_hip_device_info,
-		(void (*)(void))vfgs_hip_dev_build, (void (*)(void))vfgs_hip_init_devices, (void (*)(void))vfgs_hip_overlap_begin, (void (*)(void))vfgs_hip_overlap_end, (void (*)(void))vfgs_hip_get_stream_stats, (void (*)(void))vfgs_hip_line_lookahead, (void (*)(void))vfgs_hip_declare_frame,
+		(void (*)(void))vfgs_hip_dev_build, (void (*)(void))vfgs_hip_init_devices, (void (*)(void))vfgs_hip_overlap_begin, (void (*)(void))vfgs_hip_overlap_end, (void (*)(void))vfgs_hip_get_stream_stats, (void (*)(void))vfgs_hip_get_stripe_stream_stats, (void (*)(void))vfgs_hip_lfsr_segments, (void (*)(void))vfgs_hip_line_lookahead, (void (*)(void))vfgs_hip_declare_frame,
 		(void (*)(void))vfgs_hip_add_grain_frames_host, (void (*)(void))vfgs_hip_host_alloc, (void (*)(void))vfgs_hip_host_free, (void (*)(void))vfgs_hip_last_launch_info,
 		/* firmware interface, vfgs_fw.h:91-92, and its extensions */
 		(void (*)(void))vfgs_init_sei, (void (*)(void))vfgs_init_afgs1, (void (*)(void))vfgs_hip_generate_patterns, (void (*)(void))vfgs_hip_get_pattern,

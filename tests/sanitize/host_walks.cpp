@@ -390,6 +390,38 @@ static void walk_device_entries()
 	hipStreamDestroy(st);
 }
 
+static void walk_stripe_batches()
+{
+	// what one rank of a stripe split runs per step (vfgs_hip_add_grain_frames_part_dev): a few block rows of every frame of a batch.
+	// The library reads the LFSR windows of such a call from segments it reaches by jumps (StripeStream) -- the stub's kernel checks
+	// that every window the launch addresses lies inside the image it was handed; the image of the next call is built ahead
+	void* st = nullptr;
+	hipStreamCreateWithFlags(&st, 1);
+	program(10, 2, 2, false, true);
+	const int w = 1920, h = 1080, stride = 1920, cstride = 960, nf = 16;
+	uint64_t ss0[4], ss1[4];
+	vfgs_hip_get_stripe_stream_stats(ss0);
+	for (int rank : {0, 3, 7})
+	{
+		const int rows = 9, py = rank * rows * 16, ph = (rank == 7 ? h - py : rows * 16), crows = ph / 2;
+		DevPlanes p((size_t)stride * ph * 2 * nf, (size_t)cstride * crows * 2 * nf);
+		for (int call = 0; call < 14; call++)      // (an image holds four of these calls: the ninth finds its segments built ahead)
+		{
+			OK(vfgs_hip_add_grain_frames_part_dev(p.Y, p.U, p.V, w, h, py, ph, stride, cstride, call == 9 ? nf / 2 : nf, (size_t)stride * ph * 2, (size_t)cstride * crows * 2, st));
+			if (call == 10) OK(vfgs_hip_add_grain_frame_dev(p.Y, p.U, p.V, w, 128, stride, cstride, st));     // something else in between: the chain starts over
+			if (call == 12) vfgs_set_seed(77 + rank);                                                       // ... and a new seed
+		}
+		std::vector<vfgs_hip_frame_ptrs> list;
+		for (int f = 0; f < nf; f++) list.push_back({p.Y + (size_t)f * stride * ph * 2, p.U + (size_t)f * cstride * crows * 2, p.V + (size_t)f * cstride * crows * 2});
+		OK(vfgs_hip_add_grain_frame_list_part_dev(list.data(), nf, w, h, py, ph, stride, cstride, st));
+		hipStreamSynchronize(st);
+	}
+	vfgs_hip_get_stripe_stream_stats(ss1);
+	CHECK(ss1[3] == 1 && ss1[0] > ss0[0] && ss1[2] > ss0[2]);      // built in stream at the start of a chain, then switched to images built ahead
+	hipDeviceSynchronize();
+	hipStreamDestroy(st);
+}
+
 static void walk_refusals_and_restart()
 {
 	program(10, 2, 2, false, false);
@@ -422,6 +454,7 @@ int main(int argc, char** argv)
 		{"host_stripes_and_frames", walk_host_stripes_and_frames},
 		{"several_devices", walk_several_devices},
 		{"device_entries", walk_device_entries},
+		{"stripe_batches", walk_stripe_batches},
 		{"refusals_and_restart", walk_refusals_and_restart},
 	};
 	for (const auto& w : walks)

@@ -675,3 +675,56 @@ def test_line_api_promised_height_with_buffers_of_different_pitches(hip, monkeyp
         _line_loop(ora, b, sy)
         assert a.equal_all(b), i
         assert hip.seed_state() == ora.seed_state()
+
+
+@pytest.mark.parametrize("name,w,h,ranks,rank", [("fgs_sei_10_420", 640, 368, 8, 0), ("fgs_sei_10_420", 640, 368, 8, 5), ("fgs_sei_10_420", 640, 368, 8, 7),
+                                                 ("fgs_afgs1_test1_8_444", 520, 400, 4, 2), ("fgs_sei_ff_test6_8_422", 456, 272, 4, 1),
+                                                 ("fgs_sei_10_420", 1920, 1080, 8, 3)])
+def test_chained_stripe_batches_read_jumped_stream_segments(hip, name, w, h, ranks, rank):
+    """One rank of a stripe split over several steps (bench.py --gpus N): its stripe of `n` consecutive frames per call, call after
+    call.  Such a call reads its LFSR windows from segments the library reaches by jumps -- (nbr - 1) x nblk register steps per
+    frame, vfgs_hw.c:291-298,309-310, as one GF(2) matrix (vfgs_host.cpp StripeStream) -- and the next call's segments are built
+    ahead.  A whole-frame call in between and a new seed break the chain; results and registers are the oracle's throughout."""
+    import torch
+    from gpu_util import DevFrame, stream_ptr
+    ora, (depth, sx, sy) = program(hip, name)
+    n = 16                              # (an image of the stripe stream holds four such calls: the fifth finds its segments built ahead)
+    nbr = (h + 15) // 16
+    rows = -(-nbr // ranks)
+    py = rank * rows * 16
+    ph = min(rows * 16, h - py)
+    sz = 2 if depth > 8 else 1
+    st0 = hip.stripe_stream_stats()
+    used = 0
+    for call in range(10):
+        frames, _ = T.lcg_frames(w, h, depth, sx, sy, n, state=call + 1)
+        want = [f.copy() for f in frames]
+        for f in want:
+            ora.add_grain_frame(f)
+        f0 = frames[0]
+        cy0, cy1 = py // sy, -(-(py + ph) // sy)
+        Y = torch.from_numpy(np.stack([f.Y[py:py + ph] for f in frames]).view(np.uint8)).cuda()
+        U = torch.from_numpy(np.stack([f.U[cy0:cy1] for f in frames]).view(np.uint8)).cuda()
+        V = torch.from_numpy(np.stack([f.V[cy0:cy1] for f in frames]).view(np.uint8)).cuda()
+        hip.add_grain_frames_part_dev(Y.data_ptr(), U.data_ptr(), V.data_ptr(), w, h, py, ph, f0.stride, f0.cstride, n,
+                                      Y[0].numel(), U[0].numel(), stream_ptr())
+        used += hip.stripe_stream_stats()["last_launch_used_it"]
+        torch.cuda.synchronize()
+        for i, wf in enumerate(want):
+            assert np.array_equal(Y[i].cpu().numpy().view(wf.dtype).reshape(ph, -1), wf.Y[py:py + ph]), (call, i)
+            assert np.array_equal(U[i].cpu().numpy().view(wf.dtype).reshape(cy1 - cy0, -1), wf.U[cy0:cy1]), (call, i)
+            assert np.array_equal(V[i].cpu().numpy().view(wf.dtype).reshape(cy1 - cy0, -1), wf.V[cy0:cy1]), (call, i)
+        assert hip.seed_state() == ora.seed_state(), call
+        if call == 6:                       # something else in between: the chain starts over behind it
+            g, _ = T.lcg_frames(w, h, depth, sx, sy, 1, state=99)
+            d = DevFrame(g[0])
+            hip.add_grain_frame_dev(d.Y.data_ptr(), d.U.data_ptr(), d.V.data_ptr(), w, h, g[0].stride, g[0].cstride, stream_ptr())
+            ora.add_grain_frame(g[0])
+            assert d.download().equal_all(g[0])
+        if call == 7:
+            hip.set_seed(4711)
+            ora.set_seed(4711)
+    st1 = hip.stripe_stream_stats()
+    # (rank 0's first call after a new seed begins at bit 0, in front of which there is nothing to jump from: the ordinary window)
+    assert used >= (8 if rank == 0 else 10), used
+    assert st1["built_ahead"] > st0["built_ahead"] and st1["switches_to_built_ahead"] > st0["switches_to_built_ahead"]

@@ -108,7 +108,7 @@ def test_header_is_valid_c_and_links(lib, tmp_path):
                     f"-L{libdir}", "-lvfgs_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "54 entry points" in r.stdout and "0x00006072" in r.stdout
+    assert "56 entry points" in r.stdout and "0x00006072" in r.stdout
 
 
 def test_product_library_is_not_a_developer_build(lib):

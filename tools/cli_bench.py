@@ -40,17 +40,25 @@ def main():
             run(exe, w, h, n1, inp, out)            # (also warms the page cache)
             t2 = min(run(exe, w, h, n2, inp, out) for _ in range(2))
             md5[name] = hashlib.md5(out.read_bytes()).hexdigest()
-            t1 = min(run(exe, w, h, n1, inp, out) for _ in range(3))
-            md5[name + "_short"] = hashlib.md5(out.read_bytes()).hexdigest()
+            # short runs: plain and (for the library) with the frame height promised from outside, INTERLEAVED -- round 5 ran the
+            # three promised runs behind everything else and read an order effect of the box as a cost of the promise
+            # (profiles/r05_cli_short_runs.log vs profiles/r06_promise_probe_*.log)
+            t1s, tps = [], []
+            for _ in range(3):
+                t1s.append(run(exe, w, h, n1, inp, out))
+                md5[name + "_short"] = hashlib.md5(out.read_bytes()).hexdigest()
+                if name == "hip":
+                    tps.append(run(exe, w, h, n1, inp, out, {"VFGS_HIP_FRAME_HEIGHT": str(h)}))
+                    md5["hip_promised"] = hashlib.md5(out.read_bytes()).hexdigest()
+            t1 = min(t1s)
             per = (t2 - t1) / (n2 - n1)
             res[f"{name}_ms_per_frame_incl_file_io"] = round(per * 1e3, 2)
             res[f"{name}_frames_per_s"] = round(1 / per, 1)
-            res[f"{name}_process_s_for_{n1}_frames"] = round(t1, 2)
+            res[f"{name}_process_s_for_{n1}_frames"] = round(t1, 3)
             if name == "hip":
                 # the same unchanged binary with the frame height promised from outside: the first walk is computed ahead too
-                tp = min(run(exe, w, h, n1, inp, out, {"VFGS_HIP_FRAME_HEIGHT": str(h)}) for _ in range(3))
-                res[f"hip_process_s_for_{n1}_frames_with_VFGS_HIP_FRAME_HEIGHT"] = round(tp, 2)
-                md5["hip_promised"] = hashlib.md5(out.read_bytes()).hexdigest()
+                res[f"hip_process_s_for_{n1}_frames_with_VFGS_HIP_FRAME_HEIGHT"] = round(min(tps), 3)
+                res["hip_short_runs_s"] = {"plain": [round(t, 3) for t in t1s], "promised": [round(t, 3) for t in tps]}
             out.unlink()
         inp.unlink()
         res["identical_output"] = md5["reference"] == md5["hip"] and md5["reference_short"] == md5["hip_short"] == md5["hip_promised"]

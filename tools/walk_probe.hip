@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -178,6 +179,81 @@ __global__ __launch_bounds__(256) void walk_rows(uint8_t* buf, size_t bytes, uin
 	}
 }
 
+// Round 6 (the verdict's question: is it the BYTES THE CHIP HAS OPEN AT ONCE -- resident waves x bytes a wave still has to walk -- that
+// orders all of the results above?).  The ring again, K groups of 4 KiB per wave, but a wave's groups are NOT consecutive: the W waves
+// of a "chunk" (W = the waves the chip holds at once, or a fraction / multiple of it) interleave their groups, wave w's group g sits at
+// (g x W + w) x 4 KiB of the chunk.  Wave life, loads in flight per wave, instruction stream: those of `ring K`; what changes is that
+// at any moment the W resident waves work inside ONE contiguous window of W x 4 KiB (instead of W x K x 4 KiB) that moves through the
+// chunk as they advance together.  FRONTS = 2: two such windows (the chunk's two halves), as the grain kernel's two-frame fronts.
+template <int K, int LDS, int FRONTS>
+__global__ __launch_bounds__(256) void walk_sring(uint8_t* buf, size_t bytes, uint32_t W)
+{
+	if constexpr (LDS > 0)
+	{
+		__shared__ uint32_t pad[LDS / 4];
+		if (bytes == 1) pad[threadIdx.x] = 0;
+		if (bytes == 2) buf[0] = (uint8_t)pad[threadIdx.x ^ 1];
+	}
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t lane16 = (threadIdx.x & 63) * 16;
+	const size_t chunk = wave / W;
+	uint32_t w = (uint32_t)(wave % W);
+	const size_t cbytes = (size_t)W * K * 4096;
+	size_t cbase = chunk * cbytes;
+	uint32_t Wf = W;
+	if constexpr (FRONTS == 2)
+	{
+		// even waves sweep the chunk's first half, odd waves its second half
+		Wf = W / 2;
+		cbase += (size_t)(w & 1) * (cbytes / 2);
+		w >>= 1;
+	}
+	if (cbase >= bytes) return;
+	const __amdgpu_buffer_rsrc_t r = rsrc(buf + cbase, (uint32_t)std::min<size_t>(bytes - cbase, cbytes / FRONTS));
+	const uint32_t gstep = Wf * 4096u;
+	u32x4 v[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) v[u] = ld(r, w * 4096u + u * 1024 + lane16);
+#pragma unroll 1
+	for (int k = 0; k < K; k++)
+	{
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const u32x4 t = v[u] + 1u;
+			const uint32_t here = (uint32_t)k * gstep + w * 4096u + u * 1024 + lane16;
+			st(r, here, t);
+			v[u] = ld(r, k + 1 < K ? here + gstep : 0x80000000u);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+}
+
+template <int K, int LDS, int FRONTS>
+static double run_sring(uint8_t* buf, size_t bytes, int reps, uint32_t W)
+{
+	const size_t cbytes = (size_t)W * K * 4096;
+	const size_t use = bytes / cbytes * cbytes;          // whole chunks only
+	const size_t waves = use / ((size_t)K * 4096);
+	const unsigned grid = (unsigned)(waves / 4);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	for (int i = 0; i < 3; i++) hipLaunchKernelGGL((walk_sring<K, LDS, FRONTS>), dim3(grid), dim3(256), 0, 0, buf, use, W);
+	std::vector<float> ms;
+	for (int rep = 0; rep < reps; rep++)
+	{
+		hipEventRecord(e0);
+		hipLaunchKernelGGL((walk_sring<K, LDS, FRONTS>), dim3(grid), dim3(256), 0, 0, buf, use, W);
+		hipEventRecord(e1);
+		hipEventSynchronize(e1);
+		float t;
+		hipEventElapsedTime(&t, e0, e1);
+		ms.push_back(t);
+	}
+	std::sort(ms.begin(), ms.end());
+	return 2.0 * use / (ms[ms.size() / 2] * 1e-3) / 1e9;
+}
+
 static double run_rows(uint8_t* buf, size_t bytes, int reps, uint32_t region, size_t pitch, size_t offset)
 {
 	const size_t waves = (bytes - offset) / pitch;
@@ -264,6 +340,7 @@ static double run(uint8_t* buf, size_t bytes, int reps)
 int main(int argc, char** argv)
 {
 	const size_t bytes = (size_t)(argc > 1 ? atoi(argv[1]) : 1536) << 20;
+	const bool window_only = argc > 2 && !strcmp(argv[2], "window");
 	uint8_t* buf;
 	if (hipMalloc(&buf, bytes) != hipSuccess) return 1;
 	hipMemset(buf, 1, bytes);
@@ -271,6 +348,31 @@ int main(int argc, char** argv)
 	const int reps = 15;
 	printf("buffer %zu MiB, in place, nontemporal 16-byte accesses, GB/s (read + write) and fraction of 8 TB/s, median of %d launches\n", bytes >> 20, reps);
 #define LINE(name, MODE, K) { const double g = run<MODE, K>(buf, bytes, reps); printf("%-10s K=%-3d %8.1f  %.4f\n", name, K, g, g / 8000.0); fflush(stdout); }
+	{
+		// ---- round 6: the open window.  "open MiB" = waves the chip holds x the bytes a wave walks (what a contiguous assignment keeps
+		// open); "window MiB" = the contiguous region the resident waves work in at one moment
+		hipDeviceProp_t prop;
+		hipGetDeviceProperties(&prop, 0);
+		const int cus = prop.multiProcessorCount;
+#define LINEW(name, K, LDS, FRONTS, WMUL) { const int wpc = LDS ? 4 * (163840 / LDS) : 32; const uint32_t W = (uint32_t)(cus * wpc * WMUL); \
+			const double g = run_sring<K, LDS, FRONTS>(buf, bytes, reps, W); \
+			printf("%-8s K=%-2d %2d waves/CU  W = %5.2f x resident  fronts %d   open %6.1f MiB  window %6.1f MiB  %8.1f  %.4f\n", name, K, wpc, (double)WMUL, FRONTS, \
+			       cus * wpc * K * 4096.0 / 1048576, W * 4096.0 / FRONTS / 1048576, g, g / 8000.0); fflush(stdout); }
+#define LINEC(name, MODE, K, LDS) { const int wpc = LDS ? 4 * (163840 / LDS) : 32; const double g = run<MODE, K, LDS>(buf, bytes, reps); \
+			printf("%-8s K=%-2d %2d waves/CU  contiguous                        open %6.1f MiB  window %6.1f MiB  %8.1f  %.4f\n", name, K, wpc, \
+			       cus * wpc * K * 4096.0 / 1048576, cus * wpc * K * 4096.0 / 1048576, g, g / 8000.0); fflush(stdout); }
+		for (int round = 0; round < 2; round++)
+		{
+			LINEC("item", 0, 1, 0) LINEC("ring", 1, 2, 0) LINEC("ring", 1, 4, 0) LINEC("ring", 1, 16, 0)
+			LINEC("item", 0, 1, 40960) LINEC("ring", 1, 2, 40960) LINEC("ring", 1, 4, 40960) LINEC("ring", 1, 16, 40960) LINEC("ring", 1, 4, 54608) LINEC("ring", 1, 4, 81920)
+			LINEW("sring", 4, 0, 1, 1) LINEW("sring", 4, 0, 1, 0.5) LINEW("sring", 4, 0, 1, 2) LINEW("sring", 16, 0, 1, 1) LINEW("sring", 2, 0, 1, 1)
+			LINEW("sring", 4, 40960, 1, 1) LINEW("sring", 4, 40960, 1, 0.5) LINEW("sring", 4, 40960, 1, 0.25) LINEW("sring", 4, 40960, 1, 2) LINEW("sring", 4, 40960, 1, 4)
+			LINEW("sring", 16, 40960, 1, 1) LINEW("sring", 16, 40960, 1, 0.5) LINEW("sring", 2, 40960, 1, 1)
+			LINEW("sring", 4, 40960, 2, 1) LINEW("sring", 4, 40960, 2, 2) LINEW("sring", 16, 40960, 2, 1)
+			LINEW("sring", 4, 54608, 1, 1) LINEW("sring", 4, 81920, 1, 1)
+		}
+		if (window_only) return 0;
+	}
 	for (int round = 0; round < 2; round++)
 	{
 		LINE("item", 0, 1)

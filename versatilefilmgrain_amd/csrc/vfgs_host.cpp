@@ -105,6 +105,96 @@ uint32_t lfsr_step(uint32_t r)
 	return (r >> 1) | ((((r >> 1) ^ (r >> 29)) & 1u) << 31);
 }
 
+// ---- jump-ahead ----
+// The step of vfgs_hw.c:74-79 is linear over GF(2), so "the register n steps later" is a 32 x 32 bit matrix applied to the
+// register (column 0 is zero: bit 0 only shifts out), and n steps are log2(n) squarings of the one-step matrix.  A rank of a
+// stripe split owns a few block rows of every frame of a batch: with the matrix for one FRAME's worth of steps it visits the
+// windows it needs and never generates the rows in between (StripeStream below).
+struct LfsrMatrix {
+	uint32_t col[32];        // col[j] = image of the register with only bit j set
+	uint32_t apply(uint32_t r) const
+	{
+		uint32_t v = 0;
+		for (int j = 0; r; j++, r >>= 1) if (r & 1) v ^= col[j];
+		return v;
+	}
+	static LfsrMatrix one_step()
+	{
+		LfsrMatrix m;
+		for (int j = 0; j < 32; j++) m.col[j] = lfsr_step(1u << j);
+		return m;
+	}
+	static LfsrMatrix identity()
+	{
+		LfsrMatrix m;
+		for (int j = 0; j < 32; j++) m.col[j] = 1u << j;
+		return m;
+	}
+	LfsrMatrix then(const LfsrMatrix& b) const      // first this, then b
+	{
+		LfsrMatrix c;
+		for (int j = 0; j < 32; j++) c.col[j] = b.apply(col[j]);
+		return c;
+	}
+	static LfsrMatrix steps(uint64_t n)
+	{
+		LfsrMatrix r = identity(), p = one_step();
+		for (; n; n >>= 1)
+		{
+			if (n & 1) r = r.then(p);
+			p = p.then(p);
+		}
+		return r;
+	}
+};
+
+// a matrix as four 256-entry tables: one application = 4 loads + 3 XORs
+struct LfsrJump {
+	uint64_t nbits = ~0ull;
+	uint32_t t[4][256];
+	void build(uint64_t n)
+	{
+		if (n == nbits) return;
+		const LfsrMatrix m = LfsrMatrix::steps(n);
+		for (int k = 0; k < 4; k++)
+		{
+			t[k][0] = 0;
+			for (int v = 1; v < 256; v++) t[k][v] = t[k][v & (v - 1)] ^ m.col[8 * k + __builtin_ctz(v)];
+		}
+		nbits = n;
+	}
+	uint32_t operator()(uint32_t r) const { return t[0][r & 255] ^ t[1][(r >> 8) & 255] ^ t[2][(r >> 16) & 255] ^ t[3][r >> 24]; }
+};
+
+// words [32, n) of the stream whose first 32 words are w[0..31]: W[n] = W[n-31] ^ W[n-3], and the same recurrence squared
+// three times (W[n] = W[n-62] ^ W[n-6] from word 63 on, ... W[n] = W[n-248] ^ W[n-24] from word 249 on: 24 independent words per
+// step, which the compiler vectorises; StreamCache::fill goes on to the 32nd power for its megabyte windows)
+void lfsr_extend(uint32_t* __restrict w, size_t n)
+{
+	size_t i = 32;
+	for (; i < n && i < 63; i++) w[i] = w[i - 31] ^ w[i - 3];
+	for (; i < n && i < 125; i++) w[i] = w[i - 62] ^ w[i - 6];
+	for (; i < n && i < 249; i++) w[i] = w[i - 124] ^ w[i - 12];
+	for (; i + 24 <= n; i += 24)
+	{
+		uint32_t* __restrict d = w + i;
+		const uint32_t* __restrict a = w + i - 248;
+		const uint32_t* __restrict b = w + i - 24;
+		for (int k = 0; k < 24; k++) d[k] = a[k] ^ b[k];
+	}
+	for (; i < n; i++) w[i] = w[i - 248] ^ w[i - 24];
+}
+
+// the first 32 words of the stream that begins with register `reg` (bit by bit: once per chain of segments, ~1 us)
+void lfsr_head(uint32_t reg, uint32_t (&w)[32])
+{
+	for (int i = 0; i < 32; i++)
+	{
+		w[i] = reg;
+		for (int k = 0; k < 32; k++) reg = lfsr_step(reg);
+	}
+}
+
 // Lifetime of one image slot (LFSR stream window or table image) of a small ring.  The image is uploaded on the stream of
 // the call that needs it first and then read by kernels on whatever streams the caller uses; the slot may be overwritten
 // (pinned source and device copy) only after all of that has finished.  Steady-state launches must not pay for this --
@@ -182,6 +272,7 @@ public:
 
 	void reseed(uint32_t reg)
 	{
+		epoch_++;
 		seed_reg_ = reg;
 		ck_word_ = 0;
 		ck_reg_ = reg;
@@ -277,6 +368,14 @@ public:
 		return hipSuccess;
 	}
 
+	// a (position, register) pair someone else has computed (StripeStream's chain of jumps): a nearer point to step from
+	// than the one this cache knows, so that the next ordinary window behind a long run of stripe batches does not walk there
+	void note(uint64_t bit, uint32_t reg)
+	{
+		while (bit & 31) { reg = lfsr_step(reg); bit++; }
+		if ((bit >> 5) > ck_word_) { ck_word_ = bit >> 5; ck_reg_ = reg; }
+	}
+
 	// {refills in a caller's stream, windows built ahead on the copy stream, switches to a window built ahead, words of the current window}
 	void stats(uint64_t out[4]) const { out[0] = stats_[0]; out[1] = stats_[1]; out[2] = stats_[2]; out[3] = dev_words(); }
 
@@ -284,6 +383,7 @@ public:
 	hipError_t use(hipStream_t stream) { return cur_ < 0 ? hipSuccess : slot_[cur_].guard.use(stream); }
 
 	uint32_t seed_reg() const { return seed_reg_; }
+	uint64_t epoch() const { return epoch_; }      // counts the reloads of the register: what was built for another one is stale
 	const uint32_t* dev() const { return cur_ < 0 ? nullptr : slot_[cur_].dev; }
 	uint64_t base_bit() const { return cur_ < 0 ? 0 : slot_[cur_].wbase << 5; }
 	uint64_t dev_words() const { return cur_ < 0 ? 0 : slot_[cur_].nwords; }
@@ -369,8 +469,179 @@ private:
 #endif
 	uint64_t refill_ = kFirstRefill;
 	uint32_t seed_reg_ = 0xdeadbeefu;   // register at bit 0 (vfgs_hw.c:52-55 power-on value)
+	uint64_t epoch_ = 0;
 	uint64_t ck_word_ = 0;              // a known (word, register) point to step from
 	uint32_t ck_reg_ = 0xdeadbeefu;
+};
+
+// The stream of a BATCH OF STRIPES (vfgs_hip_add_grain_frames_part_dev and the frame-list form: what one rank of a stripe split
+// runs per step).  Frame f of the batch reads the windows of the block rows [G0 - 1, G1) it owns: nseg segments of
+// seg_words words that lie a whole frame's worth of bits apart (vfgs_hw.c:291-298,309-310: (nbr - 1) x nblk steps per frame).
+// StreamCache would build everything in between -- at eight ranks 64 whole frames = 1 MiB per call, 47-56 us of host time
+// (profiles/r05_host_overhead_weak_and_strong_shapes.log).  Here segment f + 1 is the JUMP of segment f: its first 32 words are
+// the jump matrix applied to the first 32 words of segment f (the recurrence is shift invariant, so every word jumps alike),
+// the rest follows by the word recurrence; the segments are stored back to back and the kernel simply gets seg_words x 32 as
+// its frame_bit_step.  The image of the NEXT call (the batch behind this one, same shape) is built and uploaded on the copy
+// stream right after this call's launch, as StreamCache does for its windows; a call that does not continue the chain starts
+// a new one from StreamCache::window().
+class StripeStream {
+public:
+	struct Image { const uint32_t* dev; uint32_t words; };
+
+	// segment f = stream bits [first_bit + f * step_bits, ... + 32 * seg_words), f < nseg, of the register `lfsr` was loaded with last.
+	// An image holds the segments of SEVERAL consecutive calls where a call is small (kImageSegments: a rank of a strong split
+	// takes 8 frames per call; one upload per 8 calls instead of one per call), so a call may find its segments in the middle of
+	// the current image.
+	hipError_t ensure(StreamCache& lfsr, uint64_t first_bit, uint64_t step_bits, unsigned nseg, unsigned seg_words, hipStream_t stream, Image* out)
+	{
+		hipError_t e;
+		const Key want{lfsr.epoch(), first_bit, step_bits, nseg, seg_words};
+		long at = cur_ >= 0 ? slot_[cur_].key.find(want) : -1;
+		if (at < 0 && next_ >= 0 && slot_[next_].key.find(want) >= 0)
+		{
+			if (cur_ >= 0 && (e = slot_[cur_].guard.leave()) != hipSuccess) return e;
+			cur_ = next_;
+			next_ = -1;
+			stats_[2]++;
+			at = slot_[cur_].key.find(want);
+		}
+		if (at < 0)
+		{
+			if (next_ >= 0) { if ((e = slot_[next_].guard.leave()) != hipSuccess) return e; next_ = -1; }
+			if (cur_ >= 0 && (e = slot_[cur_].guard.leave()) != hipSuccess) return e;
+			Key k = want;
+			k.nseg = nseg * std::max(1u, kImageSegments / nseg);
+			if ((e = build((last_ + 1) % kSlots, lfsr, k, stream)) != hipSuccess) { cur_ = -1; return e; }
+			cur_ = last_;
+			stats_[0]++;
+			at = 0;
+		}
+		if ((e = slot_[cur_].guard.use(stream)) != hipSuccess) return e;
+		out->dev = slot_[cur_].dev + (size_t)at * seg_words;
+		out->words = nseg * seg_words;
+		used_end_ = (unsigned)at + nseg;
+		return hipSuccess;
+	}
+
+	// after the launch: once the calls have reached the second half of the current image, the image behind it, on the copy stream
+	hipError_t prepare_next(StreamCache& lfsr)
+	{
+		if (cur_ < 0 || next_ >= 0 || !lookahead_ || slot_[cur_].key.epoch != lfsr.epoch() || used_end_ * 2 <= slot_[cur_].key.nseg) return hipSuccess;
+		Key k = slot_[cur_].key;
+		k.first_bit += (uint64_t)k.nseg * k.step_bits;
+		hipError_t e;
+		if (!copy_stream_ && (e = hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking)) != hipSuccess) return e;
+		if ((e = build((last_ + 1) % kSlots, lfsr, k, copy_stream_)) != hipSuccess) return e;
+		next_ = last_;
+		stats_[1]++;
+		return hipSuccess;
+	}
+
+	// {images built in a caller's stream, built ahead on the copy stream, switches to one built ahead}
+	void stats(uint64_t out[3]) const { out[0] = stats_[0]; out[1] = stats_[1]; out[2] = stats_[2]; }
+
+	void release()
+	{
+		for (Slot& s : slot_)
+		{
+			if (s.host) (void)hipHostFree(s.host);
+			if (s.dev) (void)hipFree(s.dev);
+			s.guard.destroy();
+			s = Slot{};
+		}
+		if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+		copy_stream_ = nullptr;
+		cur_ = next_ = -1;
+		chain_valid_ = false;
+	}
+
+	// the segments themselves, into host memory (vfgs_hip_lfsr_segments: what the tests compare with the reference's stepping)
+	void generate(StreamCache& lfsr, uint64_t first_bit, uint64_t step_bits, unsigned nseg, unsigned seg_words, uint32_t* out)
+	{
+		fill(lfsr, Key{lfsr.epoch(), first_bit, step_bits, nseg, seg_words}, out);
+	}
+
+private:
+	static constexpr int kSlots = 4;
+	static constexpr unsigned kImageSegments = 64;      // an image holds whole calls' worth of segments up to about this many
+	struct Key {
+		uint64_t epoch = 0, first_bit = 0, step_bits = 0;
+		unsigned nseg = 0, seg_words = 0;
+		// the segment of this image at which the segments `w` asks for begin, or -1
+		long find(const Key& w) const
+		{
+			if (epoch != w.epoch || step_bits != w.step_bits || seg_words != w.seg_words || w.first_bit < first_bit || !step_bits) return -1;
+			const uint64_t d = w.first_bit - first_bit;
+			if (d % step_bits || d / step_bits + w.nseg > nseg) return -1;
+			return (long)(d / step_bits);
+		}
+	};
+	struct Slot {
+		uint32_t* host = nullptr;
+		uint32_t* dev = nullptr;
+		uint64_t cap = 0;
+		Key key;
+		SlotGuard guard;
+	};
+
+	void fill(StreamCache& lfsr, const Key& k, uint32_t* out)
+	{
+		jump_.build(k.step_bits);
+		uint32_t head[32];
+		if (chain_valid_ && chain_epoch_ == k.epoch && chain_step_ == k.step_bits && chain_bit_ == k.first_bit)
+			memcpy(head, chain_head_, sizeof head);        // continues the last image: its last segment, jumped once more
+		else
+			lfsr_head(lfsr.window(k.first_bit), head);
+		for (unsigned f = 0; f < k.nseg; f++)
+		{
+			uint32_t* w = out + (size_t)f * k.seg_words;
+			memcpy(w, head, sizeof(uint32_t) * std::min<unsigned>(32, k.seg_words));
+			lfsr_extend(w, k.seg_words);
+			for (int i = 0; i < 32; i++) head[i] = jump_(head[i]);
+		}
+		memcpy(chain_head_, head, sizeof head);
+		chain_valid_ = true; chain_epoch_ = k.epoch; chain_step_ = k.step_bits;
+		chain_bit_ = k.first_bit + (uint64_t)k.nseg * k.step_bits;
+		lfsr.note(chain_bit_, head[0]);
+	}
+
+	hipError_t build(int idx, StreamCache& lfsr, const Key& k, hipStream_t stream)
+	{
+		Slot& s = slot_[idx];
+		hipError_t e;
+		if ((e = s.guard.wait_free()) != hipSuccess) return e;
+		const uint64_t n = (uint64_t)k.nseg * k.seg_words;
+		if (s.cap < n)
+		{
+			if (s.host) (void)hipHostFree(s.host);
+			if (s.dev) (void)hipFree(s.dev);
+			s.host = nullptr; s.dev = nullptr; s.cap = 0;
+			const uint64_t cap = std::max<uint64_t>(n, 1u << 15);
+			if ((e = hipHostMalloc((void**)&s.host, cap * 4, hipHostMallocDefault)) != hipSuccess) return e;
+			if ((e = hipMalloc((void**)&s.dev, cap * 4)) != hipSuccess) return e;
+			s.cap = cap;
+		}
+		fill(lfsr, k, s.host);
+		s.key = k;
+		if ((e = hipMemcpyAsync(s.dev, s.host, n * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+		last_ = idx;
+		return s.guard.uploaded(stream);
+	}
+
+	Slot slot_[kSlots];
+	int cur_ = -1, next_ = -1, last_ = -1;
+	unsigned used_end_ = 0;             // segments of the current image the calls have used up
+	hipStream_t copy_stream_ = nullptr;
+	LfsrJump jump_;
+	bool chain_valid_ = false;
+	uint64_t chain_epoch_ = 0, chain_step_ = 0, chain_bit_ = 0;
+	uint32_t chain_head_[32];
+	uint64_t stats_[3] = {0, 0, 0};
+#ifdef VFGS_NO_LOOKAHEAD
+	bool lookahead_ = false;
+#else
+	bool lookahead_ = true;
+#endif
 };
 
 // ------------------------------------------------------------------------------------
@@ -437,6 +708,8 @@ struct State {
 
 	// seed registers as positions in the stream: {rnd, rnd_up, line_rnd, line_rnd_up}
 	StreamCache lfsr;
+	StripeStream stripes;               // the stream of batches of stripes (jump-ahead; run_device)
+	bool stripe_stream_last = false;    // the last launch read its LFSR windows from `stripes`
 	uint64_t rnd = 0, rnd_up = 0, line_rnd = 0, line_rnd_up = 0;
 
 	// device
@@ -531,13 +804,17 @@ struct State {
 		struct Slot {
 			bool used = false, waited = false;
 			unsigned y0 = 0, n = 0, crow0 = 0;
-			uint8_t* in[3] = {nullptr, nullptr, nullptr};
+			uint8_t* in[3] = {nullptr, nullptr, nullptr};      // (parts of the ring's one pinned block / one device block, below)
 			uint8_t* out[3] = {nullptr, nullptr, nullptr};
-			size_t cap[3] = {0, 0, 0};
 			void* dev[3] = {nullptr, nullptr, nullptr};
-			size_t dcap[3] = {0, 0, 0};
+			size_t cap[3] = {0, 0, 0};                         // bytes each of in / out / dev [i] may hold
 			hipEvent_t up_done = nullptr, run_done = nullptr, done = nullptr;
 		} slot[kRing];
+		// ONE pinned and ONE device allocation for the whole ring: the 27 allocations this used to take (3 slots x 3 planes x
+		// in / out / device) cost the first stripe of a process 32-40 ms (profiles/r06_promise_probe_*.log)
+		uint8_t* pin = nullptr;
+		void* devblk = nullptr;
+		size_t pin_cap = 0, dev_cap = 0;
 		hipStream_t up = nullptr, run = nullptr, down = nullptr;
 		bool valid = false;
 		uint64_t gen = 0;
@@ -553,13 +830,7 @@ struct State {
 		{
 			for (Slot& sl : slot)
 			{
-				for (int i = 0; i < 3; i++)
-				{
-					if (sl.in[i]) (void)hipHostFree(sl.in[i]);
-					if (sl.out[i]) (void)hipHostFree(sl.out[i]);
-					if (sl.dev[i]) (void)hipFree(sl.dev[i]);
-					sl.in[i] = sl.out[i] = nullptr; sl.dev[i] = nullptr; sl.cap[i] = sl.dcap[i] = 0;
-				}
+				for (int i = 0; i < 3; i++) { sl.in[i] = sl.out[i] = nullptr; sl.dev[i] = nullptr; sl.cap[i] = 0; }
 				if (sl.up_done) (void)hipEventDestroy(sl.up_done);
 				if (sl.run_done) (void)hipEventDestroy(sl.run_done);
 				if (sl.done) (void)hipEventDestroy(sl.done);
@@ -570,6 +841,9 @@ struct State {
 			if (run) (void)hipStreamDestroy(run);
 			if (down) (void)hipStreamDestroy(down);
 			up = run = down = nullptr;
+			if (pin) (void)hipHostFree(pin);
+			if (devblk) (void)hipFree(devblk);
+			pin = nullptr; devblk = nullptr; pin_cap = dev_cap = 0;
 			valid = false;
 		}
 	} la;
@@ -1116,15 +1390,39 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	// Images are uploaded on the stream of the call that needs them first; a call on ANOTHER stream waits (once) for that
 	// upload, and a slot is only overwritten after all its readers (SlotGuard)
 	if (int e = upload_tables(s, stream, wide)) return e;
-	if (int e = upload_stream(s, lo, hi, stream)) return e;
 	HIP_TRY(s.tables_ring.use(stream));
-	HIP_TRY(s.lfsr.use(stream));
 	a.tables = (const uint8_t*)s.tables_ring.current();
-	a.stream = s.lfsr.dev();
-	a.stream_bytes = (uint32_t)(s.lfsr.dev_words() * 4);
-	a.cur_bit0 = (uint32_t)(first_cur - s.lfsr.base_bit());
-	a.up_bit0 = (uint32_t)(first_up - s.lfsr.base_bit());
-	a.frame_bit_step = nframes > 1 ? (uint32_t)(second_cur - first_cur) : 0;
+	// A batch of stripes that are a small part of their frames (a rank of a stripe split) reads short runs of the
+	// stream that lie a whole frame apart: those runs alone, each the jump of the one before (StripeStream).  One segment =
+	// [a word in front of the row above the stripe's first, 64 bits behind its last block].
+	const uint64_t frame_step = nframes > 1 ? second_cur - first_cur : 0;
+	const uint64_t seg_bits = 32 + (uint64_t)nblk + (uint64_t)nbr_stripe * nblk + 64;
+	const unsigned seg_words = (unsigned)((seg_bits + 31) / 32) + 1;
+	static const bool jump_on = [] { const char* e = getenv("VFGS_HIP_STRIPE_JUMP"); return !(e && e[0] == '0'); }();
+	const bool stripes = jump_on && nframes >= 2 && first_cur >= (uint64_t)nblk + 32 && first_up + nblk + 32 >= first_cur &&
+	                     (uint64_t)seg_words * 32 * 4 <= frame_step * 3;      // (the segments are at most three quarters of what lies between them)
+	s.stripe_stream_last = stripes;
+	if (stripes)
+	{
+		const uint64_t seg0 = first_cur - nblk - 32;
+		StripeStream::Image img{};
+		HIP_TRY(s.stripes.ensure(s.lfsr, seg0, frame_step, nframes, seg_words, stream, &img));
+		a.stream = img.dev;
+		a.stream_bytes = img.words * 4;
+		a.cur_bit0 = (uint32_t)(first_cur - seg0);
+		a.up_bit0 = (uint32_t)(std::max(first_up, seg0) - seg0);     // (only read where the stripe begins below the frame's first block row: the row above)
+		a.frame_bit_step = seg_words * 32;
+	}
+	else
+	{
+		if (int e = upload_stream(s, lo, hi, stream)) return e;
+		HIP_TRY(s.lfsr.use(stream));
+		a.stream = s.lfsr.dev();
+		a.stream_bytes = (uint32_t)(s.lfsr.dev_words() * 4);
+		a.cur_bit0 = (uint32_t)(first_cur - s.lfsr.base_bit());
+		a.up_bit0 = (uint32_t)(first_up - s.lfsr.base_bit());
+		a.frame_bit_step = (uint32_t)frame_step;
+	}
 
 	// one workgroup per (frame, plane, block row, part of it), numbered in memory order
 	const long per_frame = (long)a.pd[0].wgs + 2L * a.pd[1].wgs;
@@ -1162,6 +1460,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.lfronts = (!persist && nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
 #endif
 	HIP_TRY(vfgs::launch_grain(a, list, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, persist, (int)grid, stream));
+	if (stripes) HIP_TRY(s.stripes.prepare_next(s.lfsr));      // the stream of the batch behind this one, while the GPU works on this one
 	if (&s == &g_states[0])
 	{
 		vfgs_hip_launch_info& li = g_last_launch;
@@ -1491,23 +1790,8 @@ int lookahead_issue_impl(State& s, int k, unsigned y0, unsigned n)
 	lookahead_line_ptrs(s, y0, host);
 	for (int i = 0; i < 3; i++)
 	{
-		const size_t need = (size_t)la.dpitch[i] * rows[i] + 256;
-		if (sl.cap[i] < need)
-		{
-			if (sl.in[i]) HIP_TRY(hipHostFree(sl.in[i]));
-			if (sl.out[i]) HIP_TRY(hipHostFree(sl.out[i]));
-			sl.in[i] = sl.out[i] = nullptr; sl.cap[i] = 0;
-			HIP_TRY(hipHostMalloc((void**)&sl.in[i], need, hipHostMallocDefault));
-			HIP_TRY(hipHostMalloc((void**)&sl.out[i], need, hipHostMallocDefault));
-			sl.cap[i] = need;
-		}
-		if (sl.dcap[i] < need)
-		{
-			if (sl.dev[i]) HIP_TRY(hipFree(sl.dev[i]));
-			sl.dev[i] = nullptr; sl.dcap[i] = 0;
-			HIP_TRY(hipMalloc(&sl.dev[i], need));
-			sl.dcap[i] = need;
-		}
+		if ((size_t)la.dpitch[i] * rows[i] > sl.cap[i])      // (lookahead_buffers sized the slots for the largest stripe of this walk)
+			return fail(31, "look-ahead: a stripe of %u rows does not fit its ring slot", rows[i]);
 		for (unsigned r = 0; r < rows[i]; r++)   // snapshot of the caller's lines (also the H2D source)
 			memcpy(sl.in[i] + (size_t)r * la.dpitch[i], host[i] + (size_t)r * spitch[i], la.rowlen[i]);
 		HIP_TRY(hipMemcpyAsync(sl.dev[i], sl.in[i], (size_t)la.dpitch[i] * rows[i], hipMemcpyHostToDevice, la.up));
@@ -1535,6 +1819,50 @@ int lookahead_issue_impl(State& s, int k, unsigned y0, unsigned n)
 	sl.y0 = y0; sl.n = n; sl.crow0 = crow0;
 	la.issued_end = y0 + n;
 	la.stripes_issued++;
+	return 0;
+}
+
+// The ring's buffers for stripes of up to la.stripe_lines lines at the pitches of la.dpitch: one pinned block (snapshots and
+// results of every slot) and one device block, grown when a walk needs more; nothing of the ring is in flight (line_speculate
+// has drained it).
+int lookahead_buffers(State& s)
+{
+	State::LineAhead& la = s.la;
+	size_t need[3], per_slot = 0;
+	for (int i = 0; i < 3; i++)
+	{
+		const size_t rows = i ? la.stripe_lines / s.csuby + 2 : la.stripe_lines + 1;
+		need[i] = ((size_t)la.dpitch[i] * rows + 255) & ~(size_t)255;
+		per_slot += need[i];
+	}
+	const size_t pin_need = 2 * per_slot * State::LineAhead::kRing, dev_need = per_slot * State::LineAhead::kRing;
+	if (la.pin_cap < pin_need)
+	{
+		if (la.pin) HIP_TRY(hipHostFree(la.pin));
+		la.pin = nullptr; la.pin_cap = 0;
+		HIP_TRY(hipHostMalloc((void**)&la.pin, pin_need, hipHostMallocDefault));
+		la.pin_cap = pin_need;
+	}
+	if (la.dev_cap < dev_need)
+	{
+		if (la.devblk) HIP_TRY(hipFree(la.devblk));
+		la.devblk = nullptr; la.dev_cap = 0;
+		HIP_TRY(hipMalloc(&la.devblk, dev_need));
+		la.dev_cap = dev_need;
+	}
+	for (int k = 0; k < State::LineAhead::kRing; k++)
+	{
+		size_t off = 0;
+		for (int i = 0; i < 3; i++)
+		{
+			State::LineAhead::Slot& sl = la.slot[k];
+			sl.in[i] = la.pin + (size_t)k * 2 * per_slot + off;
+			sl.out[i] = la.pin + (size_t)k * 2 * per_slot + per_slot + off;
+			sl.dev[i] = (uint8_t*)la.devblk + (size_t)k * per_slot + off;
+			sl.cap[i] = need[i];
+			off += need[i];
+		}
+	}
 	return 0;
 }
 
@@ -1586,6 +1914,7 @@ int line_speculate(State& s, void* Y, void* U, void* V, unsigned y, unsigned wid
 	la.Y0 = (const uint8_t*)Y; la.U0 = (const uint8_t*)U; la.V0 = (const uint8_t*)V;
 	la.frame_end = frame_end;
 	la.stripe_lines = lookahead_stripe_lines(s, nblk);
+	if (int e = lookahead_buffers(s)) return e;
 	la.spec[0] = s.rnd; la.spec[1] = s.rnd_up; la.spec[2] = s.line_rnd; la.spec[3] = s.line_rnd_up;
 	la.head = 0;
 	la.issued_end = y;
@@ -1716,6 +2045,13 @@ int line_call(void* Y, void* U, void* V, unsigned y, unsigned width)
 		const size_t ylen = (size_t)nblk * 16 * sz, clen = (size_t)nblk * 16 / s.csubx * sz;
 		const bool ahead = la.ypitch >= (ptrdiff_t)ylen && la.cpitch >= (ptrdiff_t)clen && width > 128 && la.frame_h > y + 1;
 		rc = ahead ? line_speculate(s, Y, U, V, y, width, la.frame_h) : run_host(Y, U, V, y, width, 1, 0, 0);
+		if (ahead && rc)
+		{
+			// working ahead failed (no pinned memory for the ring, a stripe that could not be queued): the caller's registers have
+			// not moved -- stripes run from a copy of them -- so the line is computed alone, as without the look-ahead
+			la.valid = false;
+			rc = run_host(Y, U, V, y, width, 1, 0, 0);
+		}
 	}
 	la.have_prev = true;
 	la.pY = cY; la.pU = cU; la.pV = cV; la.py = y; la.pwidth = width;
@@ -1880,6 +2216,7 @@ void release_state_impl(State& s)
 				(void)hipMemcpy(s.bank[c][k], s.dev_bank + (size_t)(c * vfgs::kSlots + k) * 4096, 4096, hipMemcpyDeviceToHost);
 	s.tables_ring.release();
 	s.lfsr.release();
+	s.stripes.release();
 	for (int i = 0; i < 3; i++) { if (s.stage[i]) (void)hipFree(s.stage[i]); s.stage[i] = nullptr; s.stage_cap[i] = 0; }
 	for (int i = 0; i < 3; i++) { if (s.bounce[i]) (void)hipHostFree(s.bounce[i]); s.bounce[i] = nullptr; s.bounce_cap[i] = 0; }
 	s.pipe.release();
@@ -2484,6 +2821,27 @@ int vfgs_hip_last_launch_info(vfgs_hip_launch_info* out)
 	if (!out || !g_last_launch_valid) return -1;
 	*out = g_last_launch;
 	return 0;
+}
+
+int vfgs_hip_lfsr_segments(unsigned int reg, uint64_t first_bit, uint64_t step_bits, unsigned nseg, unsigned seg_words, uint32_t* out)
+{
+	// (host only: a generator of its own, nothing of the library's state is touched)
+	if (!out || !nseg || !seg_words) return fail(19, "vfgs_hip_lfsr_segments: nothing to fill");
+	static std::mutex mu;
+	std::lock_guard<std::mutex> g(mu);
+	static StreamCache lfsr;
+	static StripeStream gen;
+	lfsr.reseed(reg);
+	gen.generate(lfsr, first_bit, step_bits, nseg, seg_words, out);
+	return 0;
+}
+
+void vfgs_hip_get_stripe_stream_stats(uint64_t out[4])
+{
+	std::lock_guard<std::mutex> g(g_mu);
+	uint64_t st[3];
+	S().stripes.stats(st);
+	out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = S().stripe_stream_last ? 1 : 0;
 }
 
 int vfgs_hip_last_error(void) { return g_err; }

@@ -94,6 +94,9 @@ def load(path: Path | None = None) -> C.CDLL:
     lib.vfgs_hip_overlap_begin.argtypes = [vp]
     lib.vfgs_hip_get_stream_stats.argtypes = [C.POINTER(C.c_uint64)]
     lib.vfgs_hip_get_stream_stats.restype = None
+    lib.vfgs_hip_get_stripe_stream_stats.argtypes = [C.POINTER(C.c_uint64)]
+    lib.vfgs_hip_get_stripe_stream_stats.restype = None
+    lib.vfgs_hip_lfsr_segments.argtypes = [u, C.c_uint64, C.c_uint64, u, u, C.POINTER(C.c_uint32)]
     lib.vfgs_hip_overlap_end.argtypes = [vp]
     lib.vfgs_hip_add_grain_stripe_dev.argtypes = [vp, vp, vp, u, u, u, u, u, vp]
     lib.vfgs_hip_add_grain_frame_dev.argtypes = [vp, vp, vp, u, u, u, u, vp]
@@ -158,6 +161,7 @@ EXPORTS = [
     "vfgs_hip_add_grain_frame_list_copy8_dev", "vfgs_hip_get_seed_state", "vfgs_hip_get_luts", "vfgs_hip_get_params", "vfgs_hip_last_error",
     "vfgs_hip_last_error_string", "vfgs_hip_timer_begin", "vfgs_hip_timer_end", "vfgs_hip_device_info",
     "vfgs_hip_dev_build", "vfgs_hip_init_devices", "vfgs_hip_overlap_begin", "vfgs_hip_overlap_end", "vfgs_hip_get_stream_stats", "vfgs_hip_line_lookahead", "vfgs_hip_declare_frame",
+    "vfgs_hip_get_stripe_stream_stats", "vfgs_hip_lfsr_segments",
     "vfgs_hip_add_grain_frames_host", "vfgs_hip_host_alloc", "vfgs_hip_host_free", "vfgs_hip_last_launch_info",
 ]
 
@@ -301,6 +305,11 @@ class VfgsHip:
         out = (C.c_uint64 * 4)()
         self.lib.vfgs_hip_get_stream_stats(out)
         return {"refills_in_stream": out[0], "windows_built_ahead": out[1], "switches_to_built_ahead": out[2], "window_words": out[3]}
+
+    def stripe_stream_stats(self):
+        out = (C.c_uint64 * 4)()
+        self.lib.vfgs_hip_get_stripe_stream_stats(out)
+        return {"built_in_stream": out[0], "built_ahead": out[1], "switches_to_built_ahead": out[2], "last_launch_used_it": bool(out[3])}
 
     def overlap_begin(self, stream=0):
         self._ck(self.lib.vfgs_hip_overlap_begin(stream))
