@@ -1,6 +1,6 @@
 // Developer probe (round 6): what the FIRST USE of fresh HIP streams costs a process (the look-ahead of the line call creates three --
 // upload / run / download -- at its first stripe, 32-54 ms into which the ring's allocations only put 3: tools/dev/pinned_alloc_probe.cpp).
-//   hipcc -O2 -o tools/bin/stream_first_use_probe tools/dev/stream_first_use_probe.cpp && tools/bin/stream_first_use_probe
+//   hipcc -O2 --offload-arch=gfx950 -o tools/bin/stream_first_use_probe tools/dev/stream_first_use_probe.cpp && tools/bin/stream_first_use_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

@@ -816,6 +816,7 @@ struct State {
 		void* devblk = nullptr;
 		size_t pin_cap = 0, dev_cap = 0;
 		hipStream_t up = nullptr, run = nullptr, down = nullptr;
+		bool own_streams = false;             // up / run / down are streams of the look-ahead's own (else: the state's own_stream)
 		bool valid = false;
 		uint64_t gen = 0;
 		int head = 0;                         // slot of the stripe that holds line `next`
@@ -837,10 +838,14 @@ struct State {
 				sl.up_done = sl.run_done = sl.done = nullptr;
 				sl.used = sl.waited = false;
 			}
-			if (up) (void)hipStreamDestroy(up);
-			if (run) (void)hipStreamDestroy(run);
-			if (down) (void)hipStreamDestroy(down);
+			if (own_streams)
+			{
+				if (up) (void)hipStreamDestroy(up);
+				if (run) (void)hipStreamDestroy(run);
+				if (down) (void)hipStreamDestroy(down);
+			}
 			up = run = down = nullptr;
+			own_streams = false;
 			if (pin) (void)hipHostFree(pin);
 			if (devblk) (void)hipFree(devblk);
 			pin = nullptr; devblk = nullptr; pin_cap = dev_cap = 0;
@@ -1771,11 +1776,7 @@ int lookahead_issue_impl(State& s, int k, unsigned y0, unsigned n)
 	if (sl.used && !sl.waited) HIP_TRY(hipEventSynchronize(sl.done));
 	sl.used = false;
 	if (!la.up)
-	{
-		HIP_TRY(hipStreamCreateWithFlags(&la.up, hipStreamNonBlocking));
-		HIP_TRY(hipStreamCreateWithFlags(&la.run, hipStreamNonBlocking));
-		HIP_TRY(hipStreamCreateWithFlags(&la.down, hipStreamNonBlocking));
-	}
+		la.up = la.run = la.down = s.own_stream;      // (lookahead_streams: streams of its own once the process has shown that it stays)
 	if (!sl.done)
 	{
 		HIP_TRY(hipEventCreateWithFlags(&sl.up_done, hipEventDisableTiming));
@@ -1819,6 +1820,30 @@ int lookahead_issue_impl(State& s, int k, unsigned y0, unsigned n)
 	sl.y0 = y0; sl.n = n; sl.crow0 = crow0;
 	la.issued_end = y0 + n;
 	la.stripes_issued++;
+	return 0;
+}
+
+// Upload, kernel and download of the stripes run on three streams of their own, so that a stripe's download, the next one's kernel
+// and the upload of the one behind it overlap -- in a process that stays.  Three fresh streams cost a process 23-27 ms to create and
+// another 7-8 ms for the first download on one of them (profiles/r06_stream_first_use_probe.log): a tenth of a short run of the
+// unchanged CLI.  So the first kStripesOnOwnStream stripes of a process travel on the stream the single lines use (one after the
+// other: the calling thread's three passes over every byte bound the walk anyway), and the streams are created at
+// the first miss behind them.  Nothing of the ring is in flight (line_speculate has drained it).
+int lookahead_streams(State& s)
+{
+	State::LineAhead& la = s.la;
+	constexpr uint64_t kStripesOnOwnStream = 64;
+	if (la.own_streams || la.stripes_issued < kStripesOnOwnStream) return 0;
+	hipStream_t st[3] = {nullptr, nullptr, nullptr};
+	for (hipStream_t& x : st)
+		if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess)
+		{
+			(void)hipGetLastError();
+			for (hipStream_t y : st) if (y) (void)hipStreamDestroy(y);
+			return 0;      // (the stripes stay where they are)
+		}
+	la.up = st[0]; la.run = st[1]; la.down = st[2];
+	la.own_streams = true;
 	return 0;
 }
 
@@ -1915,6 +1940,7 @@ int line_speculate(State& s, void* Y, void* U, void* V, unsigned y, unsigned wid
 	la.frame_end = frame_end;
 	la.stripe_lines = lookahead_stripe_lines(s, nblk);
 	if (int e = lookahead_buffers(s)) return e;
+	if (int e = lookahead_streams(s)) return e;
 	la.spec[0] = s.rnd; la.spec[1] = s.rnd_up; la.spec[2] = s.line_rnd; la.spec[3] = s.line_rnd_up;
 	la.head = 0;
 	la.issued_end = y;
