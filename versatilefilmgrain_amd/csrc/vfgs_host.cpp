@@ -9,6 +9,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -167,22 +170,59 @@ struct LfsrJump {
 };
 
 // words [32, n) of the stream whose first 32 words are w[0..31]: W[n] = W[n-31] ^ W[n-3], and the same recurrence squared
-// three times (W[n] = W[n-62] ^ W[n-6] from word 63 on, ... W[n] = W[n-248] ^ W[n-24] from word 249 on: 24 independent words per
-// step, which the compiler vectorises; StreamCache::fill goes on to the 32nd power for its megabyte windows)
-void lfsr_extend(uint32_t* __restrict w, size_t n)
+// three times (W[n] = W[n-62] ^ W[n-6] from word 63 on, W[n] = W[n-124] ^ W[n-12] from word 125 on, W[n] = W[n-248] ^ W[n-24] from
+// word 249 on; StreamCache::fill goes on to the 32nd power for its megabyte windows).  Every phase moves chunks as long as its
+// short lag and keeps the chunk before in REGISTERS: the chain of dependent steps then costs one XOR per step instead of a store ->
+// load round trip per step, which is what bounded the plain loops (145 -> 94 ns per 531-word segment on the build host,
+// tools/dev/lfsr_extend_bench.cpp; 16-byte pieces in the long phases).
+static inline uint64_t ld64(const uint32_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline void st64(uint32_t* p, uint64_t v) { memcpy(p, &v, 8); }
+void lfsr_extend(uint32_t* w, size_t n)
 {
 	size_t i = 32;
-	for (; i < n && i < 63; i++) w[i] = w[i - 31] ^ w[i - 3];
-	for (; i < n && i < 125; i++) w[i] = w[i - 62] ^ w[i - 6];
-	for (; i < n && i < 249; i++) w[i] = w[i - 124] ^ w[i - 12];
-	for (; i + 24 <= n; i += 24)
 	{
-		uint32_t* __restrict d = w + i;
-		const uint32_t* __restrict a = w + i - 248;
-		const uint32_t* __restrict b = w + i - 24;
-		for (int k = 0; k < 24; k++) d[k] = a[k] ^ b[k];
+		uint32_t p0 = w[29], p1 = w[30], p2 = w[31];
+		for (; i + 3 <= n && i <= 62; i += 3)      // words 32 .. 64 (the base recurrence holds from word 32 on, also beyond 62)
+		{
+			p0 ^= w[i - 31]; p1 ^= w[i - 30]; p2 ^= w[i - 29];
+			w[i] = p0; w[i + 1] = p1; w[i + 2] = p2;
+		}
 	}
-	for (; i < n; i++) w[i] = w[i - 248] ^ w[i - 24];
+	if (i == 65 && i + 6 <= n)
+	{
+		uint64_t q0 = ld64(w + i - 6), q1 = ld64(w + i - 4), q2 = ld64(w + i - 2);
+		for (; i + 6 <= n && i <= 125; i += 6)     // words 65 .. 130
+		{
+			q0 ^= ld64(w + i - 62); q1 ^= ld64(w + i - 60); q2 ^= ld64(w + i - 58);
+			st64(w + i, q0); st64(w + i + 2, q1); st64(w + i + 4, q2);
+		}
+	}
+#if defined(__SSE2__)
+	if (i == 131 && i + 12 <= n)
+	{
+		__m128i r0 = _mm_loadu_si128((const __m128i*)(w + i - 12)), r1 = _mm_loadu_si128((const __m128i*)(w + i - 8)), r2 = _mm_loadu_si128((const __m128i*)(w + i - 4));
+		for (; i + 12 <= n && i <= 249; i += 12)   // words 131 .. 250
+		{
+			r0 = _mm_xor_si128(r0, _mm_loadu_si128((const __m128i*)(w + i - 124)));
+			r1 = _mm_xor_si128(r1, _mm_loadu_si128((const __m128i*)(w + i - 120)));
+			r2 = _mm_xor_si128(r2, _mm_loadu_si128((const __m128i*)(w + i - 116)));
+			_mm_storeu_si128((__m128i*)(w + i), r0); _mm_storeu_si128((__m128i*)(w + i + 4), r1); _mm_storeu_si128((__m128i*)(w + i + 8), r2);
+		}
+	}
+	if (i == 251 && i + 24 <= n)
+	{
+		__m128i r[6];
+		for (int k = 0; k < 6; k++) r[k] = _mm_loadu_si128((const __m128i*)(w + i - 24 + 4 * k));
+		for (; i + 24 <= n; i += 24)
+			for (int k = 0; k < 6; k++)
+			{
+				r[k] = _mm_xor_si128(r[k], _mm_loadu_si128((const __m128i*)(w + i - 248 + 4 * k)));
+				_mm_storeu_si128((__m128i*)(w + i + 4 * k), r[k]);
+			}
+	}
+#endif
+	// whatever the chunks left (the tail of a segment; everything behind word 130 without SSE2), word by word with the longest valid lag
+	for (; i < n; i++) w[i] = i >= 249 ? w[i - 248] ^ w[i - 24] : i >= 125 ? w[i - 124] ^ w[i - 12] : i >= 63 ? w[i - 62] ^ w[i - 6] : w[i - 31] ^ w[i - 3];
 }
 
 // the first 32 words of the stream that begins with register `reg` (bit by bit: once per chain of segments, ~1 us)
