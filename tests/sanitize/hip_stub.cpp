@@ -119,6 +119,9 @@ void vfgs_stub_stats(uint64_t out[3])
 	out[0] = g_stats_ops; out[1] = g_stats_deferred; out[2] = g_pending.size();
 }
 void vfgs_stub_set_devices(int n) { g_ndevices = n; }
+// fault injection: the next `n` pinned allocations fail (hipErrorOutOfMemory), as on a host that has run out of lockable memory
+static int g_fail_pinned = 0;
+void vfgs_stub_fail_pinned_allocs(int n) { g_fail_pinned = n; }
 
 hipError_t hipGetDeviceCount(int* n) { *n = g_ndevices; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
@@ -159,6 +162,7 @@ hipError_t hipFree(void* p)
 hipError_t hipHostMalloc(void** p, size_t n, unsigned)
 {
 	std::lock_guard<std::recursive_mutex> g(g_mu);
+	if (g_fail_pinned > 0) { g_fail_pinned--; *p = nullptr; return hipErrorOutOfMemory; }
 	*p = malloc(n ? n : 1);
 	if (!*p) return hipErrorOutOfMemory;
 	g_pinned[*p] = n;

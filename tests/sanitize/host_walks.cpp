@@ -19,6 +19,7 @@
 #include "../../include/vfgs_hip_fw.h"
 
 extern "C" void vfgs_stub_stats(uint64_t out[3]);
+extern "C" void vfgs_stub_fail_pinned_allocs(int n);
 extern "C" int hipMalloc(void** p, size_t n);
 extern "C" int hipFree(void* p);
 extern "C" int hipMemcpy(void* d, const void* s, size_t n, int kind);
@@ -422,6 +423,30 @@ static void walk_stripe_batches()
 	hipStreamDestroy(st);
 }
 
+static void walk_lookahead_without_pinned_memory()
+{
+	// The look-ahead needs pinned memory for its ring.  When the host has none to give, the drop-in call -- which returns void and would
+	// otherwise have to abort -- computes the line alone: stripes run from a COPY of the seed registers, so nothing had moved
+	// (vfgs_host.cpp line_call).  A fresh library state, so that the ring really has to be allocated; the failure is injected into the stub
+	// behind the first walk (line by line: the buffer is not proven yet, the single lines' own bounce buffers get allocated).
+	vfgs_hip_shutdown();
+	program(10, 2, 2, false, true);
+	Frame f(1280, 720, 10, 2, 2);
+	Frame before = f;
+	line_loop(f);
+	vfgs_hip_launch_info li0{}, li1{}, li2{};
+	vfgs_hip_last_launch_info(&li0);
+	vfgs_stub_fail_pinned_allocs(1 << 20);
+	for (int y = 0; y < 200; y++) vfgs_add_grain_line(f.y(y), f.u(y), f.v(y), y, f.w);
+	vfgs_hip_last_launch_info(&li1);
+	CHECK(li1.launches - li0.launches == 200);                 // every line a launch of its own: the look-ahead never got its ring
+	vfgs_stub_fail_pinned_allocs(0);
+	for (int y = 200; y < f.h; y++) vfgs_add_grain_line(f.y(y), f.u(y), f.v(y), y, f.w);
+	vfgs_hip_last_launch_info(&li2);
+	CHECK(li2.launches - li1.launches < 100);                  // ... and gets it as soon as the memory is there
+	CHECK(f.same(before));
+}
+
 static void walk_refusals_and_restart()
 {
 	program(10, 2, 2, false, false);
@@ -455,6 +480,7 @@ int main(int argc, char** argv)
 		{"several_devices", walk_several_devices},
 		{"device_entries", walk_device_entries},
 		{"stripe_batches", walk_stripe_batches},
+		{"lookahead_without_pinned", walk_lookahead_without_pinned_memory},
 		{"refusals_and_restart", walk_refusals_and_restart},
 	};
 	for (const auto& w : walks)

@@ -49,14 +49,14 @@ def test_host_layer_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     exe = build(tmp_path, "walks_asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"])
     r = run(exe, {"ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
     assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, (r.stdout[-2000:], r.stderr[-6000:])
-    assert r.stdout.count(" ok ") == 9 and "FAILED" not in r.stdout, r.stdout
+    assert r.stdout.count(" ok ") == 10 and "FAILED" not in r.stdout, r.stdout
 
 
 def test_host_layer_under_thread_sanitizer(tmp_path):
     exe = build(tmp_path, "walks_tsan", ["-fsanitize=thread"])
     r = run(exe, {"TSAN_OPTIONS": "halt_on_error=0:second_deadlock_stack=1"})
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout[-2000:], r.stderr[-6000:])
-    assert r.stdout.count(" ok ") == 9 and "FAILED" not in r.stdout, r.stdout
+    assert r.stdout.count(" ok ") == 10 and "FAILED" not in r.stdout, r.stdout
 
 
 def test_the_harness_sees_a_kernel_that_touches_one_row_too_many(tmp_path):
