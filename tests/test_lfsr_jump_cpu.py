@@ -101,3 +101,50 @@ def test_refusals(lib):
     out = (C.c_uint32 * 8)()
     assert lib.vfgs_hip_lfsr_segments(1, 0, 1, 0, 8, out) != 0
     assert lib.vfgs_hip_lfsr_segments(1, 0, 1, 1, 8, None) != 0
+
+
+def test_a_call_behind_images_built_ahead_does_not_walk_the_stream_from_bit_0(tmp_path):
+    """The stripe stream builds the image of the NEXT calls ahead and tells the contiguous window's cache how far it got.  A call of
+    another kind that takes over at the CURRENT registers then asks for a position in front of that newest known point: it must start
+    from an older one, not from the seed (a few hundred thousand frames into a stream, bit 0 is seconds away).  Host layer over the
+    HIP runtime model of tests/sanitize (no GPU): 3,000 chained 64-frame stripe calls at the 8-rank shape of 4320p, then whole frames."""
+    import os
+    import shutil
+    import subprocess
+    import time
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    csrc, inc = root / "versatilefilmgrain_amd" / "csrc", Path(os.environ.get("ROCM_PATH", "/opt/rocm")) / "include"
+    if shutil.which("g++") is None or not (inc / "hip" / "hip_runtime_api.h").exists():
+        pytest.skip("needs g++ and the HIP headers")
+    so = tmp_path / "libvfgs_host_model.so"
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", f"-I{inc}", f'-DVFGS_FW_TABLES_PATH="{csrc / "fw_tables.bin"}"',
+                        str(csrc / "vfgs_host.cpp"), str(csrc / "vfgs_fw_host.cpp"), str(csrc / "vfgs_cfg_host.cpp"), str(root / "tests" / "sanitize" / "hip_stub.cpp"),
+                        "-o", str(so), "-pthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    code = f"""
+import ctypes as C, time, sys
+lib = C.CDLL({str(so)!r})
+vp, u = C.c_void_p, C.c_uint
+lib.vfgs_hip_add_grain_frames_part_dev.argtypes = [vp, vp, vp, u, u, u, u, u, u, u, C.c_uint64, C.c_uint64, vp]
+lib.vfgs_hip_add_grain_frame_dev.argtypes = [vp, vp, vp, u, u, u, u, vp]
+lib.vfgs_hip_get_stripe_stream_stats.argtypes = [C.POINTER(C.c_uint64)]
+lib.hipMalloc.argtypes = [C.POINTER(vp), C.c_size_t]
+lib.vfgs_set_depth(10); lib.vfgs_set_chroma_subsampling(2, 2); lib.vfgs_set_scale_shift(5); lib.vfgs_set_seed(12345)
+W, H, py, ph = 7680, 4320, 544, 544
+Y, U, V = vp(), vp(), vp()
+lib.hipMalloc(C.byref(Y), W * H * 2); lib.hipMalloc(C.byref(U), W * H // 2); lib.hipMalloc(C.byref(V), W * H // 2)
+for i in range(3000):
+    assert lib.vfgs_hip_add_grain_frames_part_dev(Y, U, V, W, H, py, ph, W, W // 2, 64, 0, 0, None) == 0
+    if i % 64 == 0: lib.hipDeviceSynchronize()
+st = (C.c_uint64 * 4)(); lib.vfgs_hip_get_stripe_stream_stats(st)
+assert st[3] == 1 and st[1] > 2900, list(st)
+t0 = time.perf_counter()
+assert lib.vfgs_hip_add_grain_frame_dev(Y, U, V, W, H, W, W // 2, None) == 0      # 192,000 frames in: a contiguous window at the current registers
+dt = time.perf_counter() - t0
+lib.hipDeviceSynchronize()
+print("foreign call behind the chain: %.1f ms" % (dt * 1e3))
+sys.exit(0 if dt < 0.1 else 1)
+"""
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])

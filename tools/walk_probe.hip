@@ -229,6 +229,66 @@ __global__ __launch_bounds__(256) void walk_sring(uint8_t* buf, size_t bytes, ui
 	}
 }
 
+// Round 6, second question: is it the DISTANCE between the load and the store of the same bytes?  The ring of four register sets stores a
+// position four positions (plus the kernel's one step of lane rotation) after it asked for it; a wave needs one position per ~1.8 us, a
+// load takes ~1 us: a shallower ring covers the latency too and writes each line back sooner.  DEPTH register sets, K groups of 4 KiB per wave,
+// contiguous assignment; DEPTH = 4 is `ring`.
+template <int K, int LDS, int DEPTH>
+__global__ __launch_bounds__(256) void walk_depth(uint8_t* buf, size_t bytes)
+{
+	if constexpr (LDS > 0)
+	{
+		__shared__ uint32_t pad[LDS / 4];
+		if (bytes == 1) pad[threadIdx.x] = 0;
+		if (bytes == 2) buf[0] = (uint8_t)pad[threadIdx.x ^ 1];
+	}
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t lane16 = (threadIdx.x & 63) * 16;
+	const size_t base = wave * (size_t)K * 4096;
+	if (base >= bytes) return;
+	const __amdgpu_buffer_rsrc_t r = rsrc(buf + base, (uint32_t)std::min<size_t>(bytes - base, (size_t)K * 4096));
+	constexpr int NPOS = K * 4;
+	u32x4 v[DEPTH];
+#pragma unroll
+	for (int u = 0; u < DEPTH; u++) v[u] = ld(r, u * 1024 + lane16);
+#pragma unroll 1
+	for (int p = 0; p < NPOS; p += DEPTH)
+	{
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++)
+		{
+			const u32x4 t = v[u] + 1u;
+			const uint32_t here = (uint32_t)(p + u) * 1024 + lane16;
+			st(r, p + u < NPOS ? here : 0x80000000u, t);
+			v[u] = ld(r, p + u + DEPTH < NPOS ? here + DEPTH * 1024 : 0x80000000u);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+}
+
+template <int K, int LDS, int DEPTH>
+static double run_depth(uint8_t* buf, size_t bytes, int reps)
+{
+	const size_t waves = (bytes + (size_t)K * 4096 - 1) / ((size_t)K * 4096);
+	const unsigned grid = (unsigned)((waves + 3) / 4);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	for (int i = 0; i < 3; i++) hipLaunchKernelGGL((walk_depth<K, LDS, DEPTH>), dim3(grid), dim3(256), 0, 0, buf, bytes);
+	std::vector<float> ms;
+	for (int rep = 0; rep < reps; rep++)
+	{
+		hipEventRecord(e0);
+		hipLaunchKernelGGL((walk_depth<K, LDS, DEPTH>), dim3(grid), dim3(256), 0, 0, buf, bytes);
+		hipEventRecord(e1);
+		hipEventSynchronize(e1);
+		float t;
+		hipEventElapsedTime(&t, e0, e1);
+		ms.push_back(t);
+	}
+	std::sort(ms.begin(), ms.end());
+	return 2.0 * bytes / (ms[ms.size() / 2] * 1e-3) / 1e9;
+}
+
 template <int K, int LDS, int FRONTS>
 static double run_sring(uint8_t* buf, size_t bytes, int reps, uint32_t W)
 {
@@ -354,6 +414,7 @@ int main(int argc, char** argv)
 		hipDeviceProp_t prop;
 		hipGetDeviceProperties(&prop, 0);
 		const int cus = prop.multiProcessorCount;
+		const bool depth_only = argc > 2 && !strcmp(argv[2], "depth");
 #define LINEW(name, K, LDS, FRONTS, WMUL) { const int wpc = LDS ? 4 * (163840 / LDS) : 32; const uint32_t W = (uint32_t)(cus * wpc * WMUL); \
 			const double g = run_sring<K, LDS, FRONTS>(buf, bytes, reps, W); \
 			printf("%-8s K=%-2d %2d waves/CU  W = %5.2f x resident  fronts %d   open %6.1f MiB  window %6.1f MiB  %8.1f  %.4f\n", name, K, wpc, (double)WMUL, FRONTS, \
@@ -361,7 +422,7 @@ int main(int argc, char** argv)
 #define LINEC(name, MODE, K, LDS) { const int wpc = LDS ? 4 * (163840 / LDS) : 32; const double g = run<MODE, K, LDS>(buf, bytes, reps); \
 			printf("%-8s K=%-2d %2d waves/CU  contiguous                        open %6.1f MiB  window %6.1f MiB  %8.1f  %.4f\n", name, K, wpc, \
 			       cus * wpc * K * 4096.0 / 1048576, cus * wpc * K * 4096.0 / 1048576, g, g / 8000.0); fflush(stdout); }
-		for (int round = 0; round < 2; round++)
+		for (int round = 0; round < (depth_only ? 0 : 2); round++)
 		{
 			LINEC("item", 0, 1, 0) LINEC("ring", 1, 2, 0) LINEC("ring", 1, 4, 0) LINEC("ring", 1, 16, 0)
 			LINEC("item", 0, 1, 40960) LINEC("ring", 1, 2, 40960) LINEC("ring", 1, 4, 40960) LINEC("ring", 1, 16, 40960) LINEC("ring", 1, 4, 54608) LINEC("ring", 1, 4, 81920)
@@ -370,6 +431,20 @@ int main(int argc, char** argv)
 			LINEW("sring", 16, 40960, 1, 1) LINEW("sring", 16, 40960, 1, 0.5) LINEW("sring", 2, 40960, 1, 1)
 			LINEW("sring", 4, 40960, 2, 1) LINEW("sring", 4, 40960, 2, 2) LINEW("sring", 16, 40960, 2, 1)
 			LINEW("sring", 4, 54608, 1, 1) LINEW("sring", 4, 81920, 1, 1)
+		}
+		if (argc > 2 && !strcmp(argv[2], "depth"))
+		{
+#define LINED(K, LDS, DEPTH) { const int wpc = LDS ? 4 * (163840 / LDS) : 32; const double g = run_depth<K, LDS, DEPTH>(buf, bytes, reps); \
+			printf("depth %d  K=%-2d %2d waves/CU   a position is stored %d positions after its load was issued  %8.1f  %.4f\n", DEPTH, K, wpc, DEPTH, g, g / 8000.0); fflush(stdout); }
+			for (int round = 0; round < 2; round++)
+			{
+				LINED(4, 40960, 1) LINED(4, 40960, 2) LINED(4, 40960, 4) LINED(4, 40960, 8)
+				LINED(4, 32768, 1) LINED(4, 32768, 2) LINED(4, 32768, 4)
+				LINED(4, 0, 1) LINED(4, 0, 2) LINED(4, 0, 4)
+				LINED(16, 40960, 1) LINED(16, 40960, 2) LINED(16, 40960, 4)
+				LINED(2, 40960, 1) LINED(2, 40960, 2) LINED(2, 40960, 4)
+			}
+			return 0;
 		}
 		if (window_only) return 0;
 	}

@@ -314,8 +314,8 @@ public:
 	{
 		epoch_++;
 		seed_reg_ = reg;
-		ck_word_ = 0;
-		ck_reg_ = reg;
+		nck_ = 0;
+		checkpoint(0, reg);
 		if (cur_ >= 0) (void)slot_[cur_].guard.leave();    // kernels queued so far still read it
 		if (next_ >= 0) (void)slot_[next_].guard.leave();  // a window prepared ahead belongs to the old seed (its upload may still run)
 		cur_ = next_ = -1;   // nothing valid; slots keep their allocations
@@ -338,7 +338,8 @@ public:
 		// by the word recurrence with a 32-word ring (3 ns per 32 steps instead of per step)
 		uint64_t from = 0;
 		uint32_t reg = seed_reg_;
-		if (w >= ck_word_) { from = ck_word_; reg = ck_reg_; }
+		for (int i = 0; i < nck_; i++)          // the nearest known point at or in front of the word
+			if (ck_word_[i] <= w && ck_word_[i] >= from) { from = ck_word_[i]; reg = ck_reg_[i]; }
 		if (w - from < 40)
 		{
 			for (uint64_t n = (bit - (from << 5)); n; n--) reg = lfsr_step(reg);
@@ -375,8 +376,7 @@ public:
 			cur_ = next_;
 			next_ = -1;
 			stats_[2]++;
-			ck_word_ = slot_[cur_].wbase;
-			ck_reg_ = slot_[cur_].host[0];
+			checkpoint(slot_[cur_].wbase, slot_[cur_].host[0]);
 		}
 		if (cur_ >= 0 && wlo >= slot_[cur_].wbase && whi <= slot_[cur_].wbase + slot_[cur_].nwords)
 		{
@@ -403,8 +403,7 @@ public:
 		if ((e = fill((last_ + 1) % kSlots, wlo, n, stream)) != hipSuccess) { cur_ = -1; return e; }   // (fill reads the old window: never its own slot)
 		cur_ = last_;
 		stats_[0]++;
-		ck_word_ = wlo;
-		ck_reg_ = slot_[cur_].host[0];
+		checkpoint(wlo, slot_[cur_].host[0]);
 		return hipSuccess;
 	}
 
@@ -413,7 +412,7 @@ public:
 	void note(uint64_t bit, uint32_t reg)
 	{
 		while (bit & 31) { reg = lfsr_step(reg); bit++; }
-		if ((bit >> 5) > ck_word_) { ck_word_ = bit >> 5; ck_reg_ = reg; }
+		checkpoint(bit >> 5, reg);
 	}
 
 	// {refills in a caller's stream, windows built ahead on the copy stream, switches to a window built ahead, words of the current window}
@@ -510,8 +509,21 @@ private:
 	uint64_t refill_ = kFirstRefill;
 	uint32_t seed_reg_ = 0xdeadbeefu;   // register at bit 0 (vfgs_hw.c:52-55 power-on value)
 	uint64_t epoch_ = 0;
-	uint64_t ck_word_ = 0;              // a known (word, register) point to step from
-	uint32_t ck_reg_ = 0xdeadbeefu;
+	// Known (word, register) points to step from: the last few, because the newest may lie AHEAD of what is asked for next -- a window or a
+	// stripe image built ahead for calls that then do not come (another entry point takes over at the current registers); with one point
+	// only, such a request would walk from bit 0 (seconds, after a few hundred thousand frames)
+	static constexpr int kCheckpoints = 6;
+	uint64_t ck_word_[kCheckpoints] = {0, 0, 0, 0, 0, 0};
+	uint32_t ck_reg_[kCheckpoints] = {0xdeadbeefu, 0, 0, 0, 0, 0};
+	int nck_ = 1, ck_next_ = 1;
+	void checkpoint(uint64_t word, uint32_t reg)
+	{
+		for (int i = 0; i < nck_; i++) if (ck_word_[i] == word) return;
+		if (nck_ == 0) ck_next_ = 0;
+		ck_word_[ck_next_] = word; ck_reg_[ck_next_] = reg;
+		ck_next_ = (ck_next_ + 1) % kCheckpoints;
+		nck_ = std::min(nck_ + 1, (int)kCheckpoints);
+	}
 };
 
 // The stream of a BATCH OF STRIPES (vfgs_hip_add_grain_frames_part_dev and the frame-list form: what one rank of a stripe split

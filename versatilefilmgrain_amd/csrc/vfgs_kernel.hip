@@ -535,6 +535,10 @@ __device__ __forceinline__ void store_unit(__amdgpu_buffer_rsrc_t rs, uint32_t v
 	}
 }
 
+// register sets of a wave's ring for a plane of this depth and form (vfgs_layout.h VFGS_RING*)
+template <int DEPTH, bool ONE>
+constexpr int ring_depth() { return (DEPTH == 8 && ONE && kPk16) ? VFGS_RING_PK : ((DEPTH > 8 && ONE) ? VFGS_RING_ONE10 : VFGS_RING); }
+
 // ---------------------------------------------------------------------------------------
 // Row walk: one workgroup's share of one plane.
 //
@@ -579,7 +583,8 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 	constexpr int LDA = VFGS_LDAUX_ALIGNED, STA = VFGS_STAUX_ALIGNED;
 	constexpr int LPB = M::PAIR ? 1 : M::BPL;            // blocks per lane step (PAIR: half a block, see idx0 below)
 	constexpr int BPS = M::PAIR ? 32 : 64 * M::BPL;      // grain blocks a position advances by
-	constexpr int NU = 4;                                // positions per group = register sets of the ring
+	// positions per group = register sets of the ring = how many positions behind its load a position is stored (vfgs_layout.h)
+	constexpr int NU = ring_depth<DEPTH, ONE>();
 	constexpr int GPP = kTileBlocks / (NU * BPS);        // groups per part of a row (a part = kTileBlocks blocks = one parameter table)
 	static_assert(GPP * NU * BPS == kTileBlocks, "a part is a whole number of groups");
 	constexpr uint32_t PT_CUR = IMG_BYTES, PT_UP = IMG_BYTES + kParamTableBytes;
@@ -969,15 +974,16 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 	}
 }
 
-// Waves per SIMD the kernels are allocated for.  The 8-bit all-one-pattern kernels need 97..100 registers, one
-// allocation granule above the 96 of five waves: asking for five costs one register spilled in the prologue and reloaded
-// once per row (not in the group loop) and is worth 3 % (profiles/r03_ab22_lds_probes_and_occupancy.log); the general-form
-// kernels are held at four by their LDS image, the others by spills.
+// Waves per SIMD the kernels are allocated for.  The 8-bit all-one-pattern kernels: SIX since round 6 -- the packed 16-bit form with a
+// ring of two register sets needs 79 registers (round 5's form needed 97..100 and was held at five with one register spilled in the
+// prologue, profiles/r03_ab22_lds_probes_and_occupancy.log), and six are worth 1.4 .. 3.4 % together with the shorter ring
+// (profiles/r06_ab5_ring_depth_six_waves.log); rows walked in parts stay at four, the general-form kernels are held at four by their LDS
+// image, the others by spills.
 #ifndef VFGS_PK_WAVES
-#define VFGS_PK_WAVES 5
+#define VFGS_PK_WAVES 6       // waves per SIMD of the 8-bit all-one-pattern kernels (packed 16-bit form with a ring of two: 79 VGPRs, no spill)
 #endif
 template <int DEPTH, bool ONEY, bool ONEC, bool WIDE>
-constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && !WIDE && VFGS_WG_PER_CU == 4) ? VFGS_PK_WAVES : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
+constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && !WIDE && VFGS_WG_PER_CU == 4) ? (kPk16 ? VFGS_PK_WAVES : 5) : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
 
 // in place or out of place; workgroups numbered frame -> plane -> block row -> part of the block row
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>
@@ -1023,7 +1029,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, O
 		const int comp = 1 + (r >= a.pd[1].wgs);
 		if (comp == 2) r -= a.pd[1].wgs;
 		// horizontally subsampled chroma rows of one or two positions (2 KiB and less: 1080p at 10 bit, 2160p at 8 bit): several rows per group
-		if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 2)
+		if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 2 && ring_depth<DEPTH, ONEC>() >= 2)      // (a ring of one set cannot hold two positions of a row)
 			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 2, OUT8, WIDE, false>(a, ft, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);
 		else if (!WIDE && CSUBX == 2 && a.pd[1].rw_segs == 1)
 			run_plane_rw<DEPTH, 16 / CSUBX, CSUBX, CSUBY, L.c_rs, L.c_bytes, ONEC, L.c_neg, WIDE ? 0 : 1, OUT8, WIDE, false>(a, ft, a.pd[1], lds, comp, f, r, L.c_off[comp - 1], L.c_bank, L.c_lut[comp - 1], lane, wave);

@@ -28,6 +28,21 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_STAUX_ALIGNED
 #define VFGS_STAUX_ALIGNED 2  // ... of the sample stores
 #endif
+// Register sets of a wave's ring = positions (1 KiB wave accesses) it has in flight: a position is stored that many positions after its load
+// was issued.  Pure streams at the kernels' occupancy prefer a SHORT distance between the load and the store of the same bytes (tools/walk_probe.hip
+// depth: one set 0.775, two 0.744, four 0.727 of 8 TB/s at 16-20 waves per CU, profiles/r06_walk_ring_depth.log), the kernels need the loads of the
+// next positions in flight while they compute this one: four for the general forms and at 10 bit (two: -1 % at the headline, -3 % for the 8-bit general form),
+// two for the packed 16-bit planes of the 8-bit one-pattern kernels (+1.3 .. 3 %, and 8 VGPRs fewer: six waves per SIMD without a spill, +1.4 .. 3.4 %
+// together; profiles/r06_ab3 .. r06_ab5).
+#ifndef VFGS_RING
+#define VFGS_RING 4           // general-form planes
+#endif
+#ifndef VFGS_RING_ONE10
+#define VFGS_RING_ONE10 4     // one-pattern planes at 10 bit
+#endif
+#ifndef VFGS_RING_PK
+#define VFGS_RING_PK 2        // packed 16-bit planes (8-bit one-pattern form)
+#endif
 #ifndef VFGS_RW_CONSEC
 #define VFGS_RW_CONSEC 0      // 1 = a wave's rows are consecutive, 0 = the waves of a workgroup take every kWavesPerWG-th row
 #endif
@@ -37,7 +52,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 // other value is a build error, so a stray -D cannot produce a library that silently runs something else -- and a
 // developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
 #if !defined(VFGS_DEV_BUILD)
-#if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
+#if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_RING != 4 || VFGS_RING_ONE10 != 4 || VFGS_RING_PK != 2 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
     defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_NO_PK16) || defined(VFGS_PK_NO_READ2) || defined(VFGS_PK_WAVES) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS) || defined(VFGS_PERSIST_MAX_WG_KB)
 #error "libvfgs_hip: a tuning knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
