@@ -983,7 +983,13 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 #define VFGS_PK_WAVES 6       // waves per SIMD of the 8-bit all-one-pattern kernels (packed 16-bit form with a ring of two: 79 VGPRs, no spill)
 #endif
 template <int DEPTH, bool ONEY, bool ONEC, bool WIDE>
-constexpr int rw_waves_per_simd() { return (DEPTH == 8 && ONEY && ONEC && !WIDE && VFGS_WG_PER_CU == 4) ? (kPk16 ? VFGS_PK_WAVES : 5) : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4; }
+constexpr int rw_waves_per_simd()
+{
+#ifdef VFGS_ONE10_WAVES      // developer A/B: the 10-bit all-one-pattern kernels at another occupancy
+	if (DEPTH == 10 && ONEY && ONEC && !WIDE) return VFGS_ONE10_WAVES;
+#endif
+	return (DEPTH == 8 && ONEY && ONEC && !WIDE && VFGS_WG_PER_CU == 4) ? (kPk16 ? VFGS_PK_WAVES : 5) : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4;
+}
 
 // in place or out of place; workgroups numbered frame -> plane -> block row -> part of the block row
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>

@@ -53,7 +53,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 // developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
 #if !defined(VFGS_DEV_BUILD)
 #if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_RING != 4 || VFGS_RING_ONE10 != 4 || VFGS_RING_PK != 2 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
-    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_NO_PK16) || defined(VFGS_PK_NO_READ2) || defined(VFGS_PK_WAVES) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS) || defined(VFGS_PERSIST_MAX_WG_KB)
+    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_NO_PK16) || defined(VFGS_PK_NO_READ2) || defined(VFGS_PK_WAVES) || defined(VFGS_ONE10_WAVES) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS) || defined(VFGS_PERSIST_MAX_WG_KB)
 #error "libvfgs_hip: a tuning knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
 #endif
