@@ -584,7 +584,8 @@ __device__ __forceinline__ void run_plane_rw(const KernelArgs& a, const FrameTab
 	constexpr int LPB = M::PAIR ? 1 : M::BPL;            // blocks per lane step (PAIR: half a block, see idx0 below)
 	constexpr int BPS = M::PAIR ? 32 : 64 * M::BPL;      // grain blocks a position advances by
 	// positions per group = register sets of the ring = how many positions behind its load a position is stored (vfgs_layout.h)
-	constexpr int NU = ring_depth<DEPTH, ONE>();
+	// (narrow one-pattern planes at 10 bit -- rows of one or two positions: the chroma of 1080p -- walk with a ring of their own depth: vfgs_layout.h)
+	constexpr int NU = (DEPTH > 8 && ONE && NARROW != 0) ? VFGS_RING_NARROW10 : ring_depth<DEPTH, ONE>();
 	constexpr int GPP = kTileBlocks / (NU * BPS);        // groups per part of a row (a part = kTileBlocks blocks = one parameter table)
 	static_assert(GPP * NU * BPS == kTileBlocks, "a part is a whole number of groups");
 	constexpr uint32_t PT_CUR = IMG_BYTES, PT_UP = IMG_BYTES + kParamTableBytes;

@@ -43,6 +43,9 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_RING_PK
 #define VFGS_RING_PK 2        // packed 16-bit planes (8-bit one-pattern form)
 #endif
+#ifndef VFGS_RING_NARROW10
+#define VFGS_RING_NARROW10 2  // one-pattern planes at 10 bit whose rows are one or two positions (1080p chroma): 1080p fgs_sei +2.4 % at 8, +1.1 % at 32 frames per launch, ff_test1 +0 .. 0.3 % (profiles/r06_ab8)
+#endif
 #ifndef VFGS_RW_CONSEC
 #define VFGS_RW_CONSEC 0      // 1 = a wave's rows are consecutive, 0 = the waves of a workgroup take every kWavesPerWG-th row
 #endif
@@ -52,7 +55,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 // other value is a build error, so a stray -D cannot produce a library that silently runs something else -- and a
 // developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
 #if !defined(VFGS_DEV_BUILD)
-#if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_RING != 4 || VFGS_RING_ONE10 != 4 || VFGS_RING_PK != 2 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
+#if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_RING != 4 || VFGS_RING_ONE10 != 4 || VFGS_RING_PK != 2 || VFGS_RING_NARROW10 != 2 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
     defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_NO_PK16) || defined(VFGS_PK_NO_READ2) || defined(VFGS_PK_WAVES) || defined(VFGS_ONE10_WAVES) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS) || defined(VFGS_PERSIST_MAX_WG_KB)
 #error "libvfgs_hip: a tuning knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
