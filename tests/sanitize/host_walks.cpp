@@ -417,6 +417,12 @@ static void walk_stripe_batches()
 		OK(vfgs_hip_add_grain_frame_list_part_dev(list.data(), nf, w, h, py, ph, stride, cstride, st));
 		hipStreamSynchronize(st);
 	}
+	// the generator on its own, with segments shorter than the 32 jumped words (tiny pictures) and exactly sized buffers
+	for (unsigned nw : {1u, 5u, 31u, 32u, 33u, 64u, 66u, 131u, 250u, 251u, 275u, 531u})
+	{
+		std::vector<uint32_t> seg((size_t)7 * nw);
+		OK(vfgs_hip_lfsr_segments(12345u << 1, 1000, 4099, 7, nw, seg.data()));
+	}
 	vfgs_hip_get_stripe_stream_stats(ss1);
 	CHECK(ss1[3] == 1 && ss1[0] > ss0[0] && ss1[2] > ss0[2]);      // built in stream at the start of a chain, then switched to images built ahead
 	hipDeviceSynchronize();

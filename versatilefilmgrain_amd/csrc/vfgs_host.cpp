@@ -179,6 +179,7 @@ static inline uint64_t ld64(const uint32_t* p) { uint64_t v; memcpy(&v, p, 8); r
 static inline void st64(uint32_t* p, uint64_t v) { memcpy(p, &v, 8); }
 void lfsr_extend(uint32_t* w, size_t n)
 {
+	if (n <= 32) return;       // (a segment shorter than its head: nothing to extend, and w[29..31] may not be the caller's)
 	size_t i = 32;
 	{
 		uint32_t p0 = w[29], p1 = w[30], p2 = w[31];
@@ -533,9 +534,9 @@ private:
 // (profiles/r05_host_overhead_weak_and_strong_shapes.log).  Here segment f + 1 is the JUMP of segment f: its first 32 words are
 // the jump matrix applied to the first 32 words of segment f (the recurrence is shift invariant, so every word jumps alike),
 // the rest follows by the word recurrence; the segments are stored back to back and the kernel simply gets seg_words x 32 as
-// its frame_bit_step.  The image of the NEXT call (the batch behind this one, same shape) is built and uploaded on the copy
-// stream right after this call's launch, as StreamCache does for its windows; a call that does not continue the chain starts
-// a new one from StreamCache::window().
+// its frame_bit_step.  The image of the NEXT calls (the batches behind this one, same shape) is built and uploaded on the copy
+// stream once the calls have reached the second half of the current one, as StreamCache does for its windows; a call that does
+// not continue the chain starts a new one from StreamCache::window().
 class StripeStream {
 public:
 	struct Image { const uint32_t* dev; uint32_t words; };
@@ -1517,7 +1518,9 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 	a.lfronts = (!persist && nframes >= 2 && !in_region && 2 * (yext + 2 * cext) >= (64u << 20)) ? 1 : 0;
 #endif
 	HIP_TRY(vfgs::launch_grain(a, list, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, persist, (int)grid, stream));
-	if (stripes) HIP_TRY(s.stripes.prepare_next(s.lfsr));      // the stream of the batch behind this one, while the GPU works on this one
+	// the stream of the batches behind this one, while the GPU works on this one.  (Failing to work ahead is not a failure of THIS call, which is
+	// queued and whose registers have moved: the next call then builds its image in its own stream.)
+	if (stripes && s.stripes.prepare_next(s.lfsr) != hipSuccess) (void)hipGetLastError();
 	if (&s == &g_states[0])
 	{
 		vfgs_hip_launch_info& li = g_last_launch;
