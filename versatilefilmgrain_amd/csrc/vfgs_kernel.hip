@@ -1091,21 +1091,44 @@ static hipError_t launch_form(const KernelArgs& a, const FrameTable& ft, bool on
 // chroma (vfgs_layout.h); wide: rows of more than kTileBlocks blocks (launch_form: which forms exist); persist: a.persist_wgs luma workgroups
 // share the launch's luma tasks (10 bit, general-form luma, not wide), grid = persist_wgs + all chroma tasks; else grid =
 // workgroups per frame
+//
+// The product compiles this file TWICE (versatilefilmgrain_amd/build.py: -DVFGS_KERNEL_DEPTH=10 and =8), side by side: one code object per
+// sample depth, 56 + 32 kernels.  That halves the build (110 -> 60 s) and keeps the other depth's kernels off the device; it does NOT buy the
+// start-up time round 5 hoped for: a code object's first launch costs 1.3 ms (profiles/r06_startup_probe_two_code_objects.jsonl), so the 15 ms
+// of a process's first grain launch are the allocations and first transfers around it, not the 88 kernels.  Without the macro (the assembly
+// listings) everything is one translation unit.
+template <int D>
+static hipError_t launch_depth(const KernelArgs& a, const FrameTable& ft, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
+{
+#define VFGS_CASE(X, Y)                                                                                                     \
+	if (csubx == X && csuby == Y)                                                                                           \
+	{                                                                                                                       \
+		if constexpr (D == 10) { if (out8) return launch_form<D, X, Y, true>(a, ft, oney, onec, wide, persist, grid, stream); } \
+		return launch_form<D, X, Y, false>(a, ft, oney, onec, wide, persist, grid, stream);                                     \
+	}
+	VFGS_CASE(2, 2) VFGS_CASE(2, 1) VFGS_CASE(1, 1) VFGS_CASE(1, 2)
+#undef VFGS_CASE
+	return hipErrorInvalidValue;
+}
+
+#if !defined(VFGS_KERNEL_DEPTH) || VFGS_KERNEL_DEPTH == 8
+hipError_t launch_grain_d8(const KernelArgs& a, const FrameTable& ft, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
+{
+	return launch_depth<8>(a, ft, csubx, csuby, out8, oney, onec, wide, persist, grid, stream);
+}
+#else
+hipError_t launch_grain_d8(const KernelArgs& a, const FrameTable& ft, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream);
+#endif
+
+#if !defined(VFGS_KERNEL_DEPTH) || VFGS_KERNEL_DEPTH == 10
 hipError_t launch_grain(const KernelArgs& a, const FrameTable* list, int depth, int csubx, int csuby, bool out8, bool oney, bool onec, bool wide, bool persist, int grid, hipStream_t stream)
 {
 	if ((out8 && depth != 10) || wide != (a.nblk > kTileBlocks)) return hipErrorInvalidValue;
 	if ((a.listed != 0) != (list != nullptr) || (list && a.nframes > kListFrames)) return hipErrorInvalidValue;
 	static const FrameTable no_list{};
 	const FrameTable& ft = list ? *list : no_list;
-#define VFGS_CASE(D, X, Y)                                                                                                  \
-	if (depth == D && csubx == X && csuby == Y)                                                                             \
-	{                                                                                                                       \
-		if constexpr (D == 10) { if (out8) return launch_form<D, X, Y, true>(a, ft, oney, onec, wide, persist, grid, stream); } \
-		return launch_form<D, X, Y, false>(a, ft, oney, onec, wide, persist, grid, stream);                                     \
-	}
-	VFGS_CASE(10, 2, 2) VFGS_CASE(10, 2, 1) VFGS_CASE(10, 1, 1) VFGS_CASE(10, 1, 2)
-	VFGS_CASE(8, 2, 2) VFGS_CASE(8, 2, 1) VFGS_CASE(8, 1, 1) VFGS_CASE(8, 1, 2)
-#undef VFGS_CASE
+	if (depth == 10) return launch_depth<10>(a, ft, csubx, csuby, out8, oney, onec, wide, persist, grid, stream);
+	if (depth == 8) return launch_grain_d8(a, ft, csubx, csuby, out8, oney, onec, wide, persist, grid, stream);
 	return hipErrorInvalidValue;
 }
 
@@ -1117,5 +1140,6 @@ void describe_launch(char* out, size_t n, int depth, int csubx, int csuby, bool 
 }
 
 ImageLayout layout_of(int csubx, int csuby, bool oney, bool onec, bool depth8) { return image_layout(csubx, csuby, oney, onec, depth8); }
+#endif
 
 }  // namespace vfgs
