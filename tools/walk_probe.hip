@@ -266,19 +266,137 @@ __global__ __launch_bounds__(256) void walk_depth(uint8_t* buf, size_t bytes)
 	}
 }
 
+// ... and with the kernel's ONE MORE position of delay: the lanes compute bytes shifted against the units they move, so a position's units are
+// complete only when the NEXT position has been computed (vfgs_kernel.hip: lane rotation) -- the store of position p is issued at step p + 1.
 template <int K, int LDS, int DEPTH>
+__global__ __launch_bounds__(256) void walk_depth_lag(uint8_t* buf, size_t bytes)
+{
+	if constexpr (LDS > 0)
+	{
+		__shared__ uint32_t pad[LDS / 4];
+		if (bytes == 1) pad[threadIdx.x] = 0;
+		if (bytes == 2) buf[0] = (uint8_t)pad[threadIdx.x ^ 1];
+	}
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t lane16 = (threadIdx.x & 63) * 16;
+	const size_t base = wave * (size_t)K * 4096;
+	if (base >= bytes) return;
+	const __amdgpu_buffer_rsrc_t r = rsrc(buf + base, (uint32_t)std::min<size_t>(bytes - base, (size_t)K * 4096));
+	constexpr int NPOS = K * 4;
+	u32x4 v[DEPTH];
+	u32x4 prev = {0u, 0u, 0u, 0u};
+#pragma unroll
+	for (int u = 0; u < DEPTH; u++) v[u] = ld(r, u * 1024 + lane16);
+#pragma unroll 1
+	for (int p = 0; p < NPOS; p += DEPTH)
+	{
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++)
+		{
+			const u32x4 t = v[u] + 1u;                                      // (waits for position p + u)
+			const uint32_t here = (uint32_t)(p + u) * 1024 + lane16;
+			v[u] = ld(r, p + u + DEPTH < NPOS ? here + DEPTH * 1024 : 0x80000000u);
+			st(r, p + u > 0 ? here - 1024 : 0x80000000u, prev);            // the position BEFORE this one
+			prev = t;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	st(r, (uint32_t)(NPOS - 1) * 1024 + lane16, prev);
+}
+
+// ... and with arithmetic between the load and the store, in the kernel's order: wait for position p, ask for position p + DEPTH, compute
+// (`work` rounds of four dependent v_mad_u32_u24; the 10-bit luma kernel spends ~95 vector instructions per position: work = 24), store
+// position p - 1.  Does the shallow ring keep its advantage when the wave has something to do while its load is in flight?
+template <int K, int LDS, int DEPTH>
+__global__ __launch_bounds__(256) void walk_depth_work(uint8_t* buf, size_t bytes, int work, int stages)
+{
+	static_assert(LDS >= 16384, "the gathers below index 16 KiB");
+	__shared__ uint32_t pad[LDS / 4];
+	for (int i = threadIdx.x; i < 4096; i += 256) pad[i] = 0;      // (zeros: the gathers below leave the data alone)
+	__syncthreads();
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t lane16 = (threadIdx.x & 63) * 16;
+	const size_t base = wave * (size_t)K * 4096;
+	if (base >= bytes) return;
+	const __amdgpu_buffer_rsrc_t r = rsrc(buf + base, (uint32_t)std::min<size_t>(bytes - base, (size_t)K * 4096));
+	constexpr int NPOS = K * 4;
+	u32x4 v[DEPTH];
+	u32x4 prev = {0u, 0u, 0u, 0u};
+#pragma unroll
+	for (int u = 0; u < DEPTH; u++) v[u] = ld(r, u * 1024 + lane16);
+#pragma unroll 1
+	for (int p = 0; p < NPOS; p += DEPTH)
+	{
+#pragma unroll
+		for (int u = 0; u < DEPTH; u++)
+		{
+			u32x4 t = v[u] + 1u;
+			const uint32_t here = (uint32_t)(p + u) * 1024 + lane16;
+			v[u] = ld(r, p + u + DEPTH < NPOS ? here + DEPTH * 1024 : 0x80000000u);
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+			for (int i = 0; i < work; i++)
+			{
+				t.x = __umul24(t.x, 0x10001u) + 0x9e37u; t.y = __umul24(t.y, 0x10001u) + 0x79b9u;
+				t.z = __umul24(t.z, 0x10001u) + 0x7f4au; t.w = __umul24(t.w, 0x10001u) + 0x7c15u;
+			}
+			// `stages` dependent round trips to LDS, four scattered dword gathers each (the kernel: block parameters -> scale / pattern
+			// look-ups -> bank rows: three to four)
+#pragma unroll 1
+			for (int i = 0; i < stages; i++)
+			{
+				const uint32_t x = pad[t.x & 4095], y = pad[t.y & 4095], z = pad[t.z & 4095], q = pad[t.w & 4095];
+				t.x += y; t.y += z; t.z += q; t.w += x;
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			st(r, p + u > 0 ? here - 1024 : 0x80000000u, prev);
+			prev = t;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	st(r, (uint32_t)(NPOS - 1) * 1024 + lane16, prev);
+}
+
+template <int K, int LDS, int DEPTH>
+static double run_depth_work(uint8_t* buf, size_t bytes, int reps, int work, int stages = 0)
+{
+	const size_t waves = (bytes + (size_t)K * 4096 - 1) / ((size_t)K * 4096);
+	const unsigned grid = (unsigned)((waves + 3) / 4);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	for (int i = 0; i < 3; i++) hipLaunchKernelGGL((walk_depth_work<K, LDS, DEPTH>), dim3(grid), dim3(256), 0, 0, buf, bytes, work, stages);
+	std::vector<float> ms;
+	for (int rep = 0; rep < reps; rep++)
+	{
+		hipEventRecord(e0);
+		hipLaunchKernelGGL((walk_depth_work<K, LDS, DEPTH>), dim3(grid), dim3(256), 0, 0, buf, bytes, work, stages);
+		hipEventRecord(e1);
+		hipEventSynchronize(e1);
+		float t;
+		hipEventElapsedTime(&t, e0, e1);
+		ms.push_back(t);
+	}
+	std::sort(ms.begin(), ms.end());
+	return 2.0 * bytes / (ms[ms.size() / 2] * 1e-3) / 1e9;
+}
+
+template <int K, int LDS, int DEPTH, bool LAG = false>
 static double run_depth(uint8_t* buf, size_t bytes, int reps)
 {
 	const size_t waves = (bytes + (size_t)K * 4096 - 1) / ((size_t)K * 4096);
 	const unsigned grid = (unsigned)((waves + 3) / 4);
 	hipEvent_t e0, e1;
 	hipEventCreate(&e0); hipEventCreate(&e1);
-	for (int i = 0; i < 3; i++) hipLaunchKernelGGL((walk_depth<K, LDS, DEPTH>), dim3(grid), dim3(256), 0, 0, buf, bytes);
+	auto launch = [&] {
+		if constexpr (LAG) hipLaunchKernelGGL((walk_depth_lag<K, LDS, DEPTH>), dim3(grid), dim3(256), 0, 0, buf, bytes);
+		else hipLaunchKernelGGL((walk_depth<K, LDS, DEPTH>), dim3(grid), dim3(256), 0, 0, buf, bytes);
+	};
+	for (int i = 0; i < 3; i++) launch();
 	std::vector<float> ms;
 	for (int rep = 0; rep < reps; rep++)
 	{
 		hipEventRecord(e0);
-		hipLaunchKernelGGL((walk_depth<K, LDS, DEPTH>), dim3(grid), dim3(256), 0, 0, buf, bytes);
+		launch();
 		hipEventRecord(e1);
 		hipEventSynchronize(e1);
 		float t;
@@ -441,6 +559,25 @@ int main(int argc, char** argv)
 				LINED(4, 40960, 1) LINED(4, 40960, 2) LINED(4, 40960, 4) LINED(4, 40960, 8)
 				LINED(4, 32768, 1) LINED(4, 32768, 2) LINED(4, 32768, 4)
 				LINED(4, 0, 1) LINED(4, 0, 2) LINED(4, 0, 4)
+#define LINEDL(K, LDS, DEPTH) { const int wpc = LDS ? 4 * (163840 / LDS) : 32; const double g = run_depth<K, LDS, DEPTH, true>(buf, bytes, reps); \
+			printf("depth %d  K=%-2d %2d waves/CU   ... and stored one position later still (the kernel's lane rotation): %d positions after its load  %8.1f  %.4f\n", DEPTH, K, wpc, DEPTH + 1, g, g / 8000.0); fflush(stdout); }
+				LINEDL(4, 40960, 1) LINEDL(4, 40960, 2) LINEDL(4, 40960, 4) LINEDL(4, 32768, 1) LINEDL(4, 32768, 2) LINEDL(4, 32768, 4)
+#define LINEDW(K, LDS, DEPTH, WORK) { const int wpc = LDS ? 4 * (163840 / LDS) : 32; const double g = run_depth_work<K, LDS, DEPTH>(buf, bytes, reps, WORK); \
+			printf("depth %d  K=%-2d %2d waves/CU   kernel order, %3d vector instructions per position between load and store  %8.1f  %.4f\n", DEPTH, K, wpc, 4 * WORK, g, g / 8000.0); fflush(stdout); }
+				LINEDW(4, 32768, 1, 0) LINEDW(4, 32768, 1, 12) LINEDW(4, 32768, 1, 24) LINEDW(4, 32768, 1, 48) LINEDW(4, 32768, 1, 96)
+				LINEDW(4, 32768, 2, 0) LINEDW(4, 32768, 2, 12) LINEDW(4, 32768, 2, 24) LINEDW(4, 32768, 2, 48) LINEDW(4, 32768, 2, 96)
+				LINEDW(4, 32768, 4, 0) LINEDW(4, 32768, 4, 12) LINEDW(4, 32768, 4, 24) LINEDW(4, 32768, 4, 48) LINEDW(4, 32768, 4, 96)
+				LINEDW(2, 32768, 1, 24) LINEDW(2, 32768, 2, 24) LINEDW(2, 32768, 4, 24)
+#define LINEDS(K, LDS, DEPTH, WORK, ST) { const int wpc = LDS ? 4 * (163840 / LDS) : 32; const double g = run_depth_work<K, LDS, DEPTH>(buf, bytes, reps, WORK, ST); \
+			printf("depth %d  K=%-2d %2d waves/CU   kernel order, %3d vector instructions and %d dependent LDS round trips per position  %8.1f  %.4f\n", DEPTH, K, wpc, 4 * WORK, ST, g, g / 8000.0); fflush(stdout); }
+				LINEDS(4, 32768, 1, 16, 2) LINEDS(4, 32768, 1, 16, 4) LINEDS(4, 32768, 1, 16, 8)
+				LINEDS(4, 32768, 2, 16, 2) LINEDS(4, 32768, 2, 16, 4) LINEDS(4, 32768, 2, 16, 8)
+				LINEDS(4, 32768, 4, 16, 2) LINEDS(4, 32768, 4, 16, 4) LINEDS(4, 32768, 4, 16, 8)
+				// fewer waves, deeper rings: the same loads in flight per CU
+				LINEDS(4, 53248, 1, 16, 2) LINEDS(4, 53248, 2, 16, 2) LINEDS(4, 53248, 4, 16, 2)
+				LINEDS(4, 65536, 1, 16, 2) LINEDS(4, 65536, 2, 16, 2) LINEDS(4, 65536, 4, 16, 2) LINEDS(8, 65536, 8, 16, 2)
+				LINEDS(8, 32768, 1, 16, 2) LINEDS(8, 32768, 2, 16, 2) LINEDS(8, 32768, 4, 16, 2)
+				LINEDS(8, 65536, 1, 16, 2) LINEDS(8, 65536, 2, 16, 2) LINEDS(8, 65536, 4, 16, 2)
 				LINED(16, 40960, 1) LINED(16, 40960, 2) LINED(16, 40960, 4)
 				LINED(2, 40960, 1) LINED(2, 40960, 2) LINED(2, 40960, 4)
 			}

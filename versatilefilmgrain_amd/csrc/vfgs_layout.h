@@ -46,6 +46,18 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_RING_NARROW10
 #define VFGS_RING_NARROW10 2  // one-pattern planes at 10 bit whose rows are one or two positions (1080p chroma): 1080p fgs_sei +2.4 % at 8, +1.1 % at 32 frames per launch, ff_test1 +0 .. 0.3 % (profiles/r06_ab8)
 #endif
+// Resident workgroups per CU of the all-one-pattern kernels, held there by unused LDS behind their tables (vfgs_kernel.hip lds_pad; 0 = as many as fit).
+// Their 15 KB of LDS and ~80 registers would let SIX in: 24 waves with four 1 KiB loads each in flight per CU, and the memory system answers a CU
+// that asks for less at once better (tools/walk_probe.hip depth: 20-24 KiB of loads in flight per CU stream at 0.79-0.80 of 8 TB/s, 64-96 KiB at
+// 0.73-0.75).  At 10 bit FOUR are worth +1.5 .. 4 % from 720p to 4320p (three: up to +5.7 % at 1080p / 2160p, -5 % at 720p;
+// profiles/r06_ab13_workgroups_per_cu.log, r06_ab14_workgroups_per_cu_sizes.log); the 8-bit kernels (twice the arithmetic per byte) lose 2-3 % at five
+// and four and keep their six.  The general-form kernels are at four by their 40 KB image, and three cost them 2.5 % (r06_ab11).
+#ifndef VFGS_ONE10_WG_PER_CU
+#define VFGS_ONE10_WG_PER_CU 4
+#endif
+#ifndef VFGS_ONE8_WG_PER_CU
+#define VFGS_ONE8_WG_PER_CU 0
+#endif
 #ifndef VFGS_RW_CONSEC
 #define VFGS_RW_CONSEC 0      // 1 = a wave's rows are consecutive, 0 = the waves of a workgroup take every kWavesPerWG-th row
 #endif
@@ -55,8 +67,8 @@ constexpr int kBlock = 16;       // luma samples per grain block
 // other value is a build error, so a stray -D cannot produce a library that silently runs something else -- and a
 // developer build says so at run time (vfgs_hip_dev_build(), refused by versatilefilmgrain_amd.hw unless asked for).
 #if !defined(VFGS_DEV_BUILD)
-#if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_RING != 4 || VFGS_RING_ONE10 != 4 || VFGS_RING_PK != 2 || VFGS_RING_NARROW10 != 2 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
-    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_NO_PK16) || defined(VFGS_PK_NO_READ2) || defined(VFGS_PK_WAVES) || defined(VFGS_ONE10_WAVES) || defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS) || defined(VFGS_PERSIST_MAX_WG_KB)
+#if VFGS_WAVES != 4 || VFGS_WG_PER_CU != 4 || VFGS_RING != 4 || VFGS_RING_ONE10 != 4 || VFGS_RING_PK != 2 || VFGS_RING_NARROW10 != 2 || VFGS_ONE10_WG_PER_CU != 4 || VFGS_ONE8_WG_PER_CU != 0 || VFGS_SCHED_FENCE != 1 || VFGS_LDAUX_ALIGNED != 2 || VFGS_STAUX_ALIGNED != 2 || VFGS_RW_CONSEC != 0 || \
+    defined(VFGS_NO_FRONTS) || defined(VFGS_NO_LOOKAHEAD) || defined(VFGS_NO_ONE_PATTERN) || defined(VFGS_NO_PK16) || defined(VFGS_PK_NO_READ2) || defined(VFGS_PK_WAVES) || defined(VFGS_ONE10_WAVES) ||  defined(VFGS_RW_WG_BYTES) || defined(VFGS_RW_MIN_FILL_PCT) || defined(VFGS_PERSIST_MIN_TASKS) || defined(VFGS_PERSIST_MAX_WG_KB)
 #error "libvfgs_hip: a tuning knob differs from the shipped configuration; developer variants must define VFGS_DEV_BUILD"
 #endif
 #endif
