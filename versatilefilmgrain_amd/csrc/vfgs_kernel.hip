@@ -999,7 +999,8 @@ template <int DEPTH, bool ONEY, bool ONEC, bool WIDE>
 constexpr int lds_pad(const int need)
 {
 	constexpr int kLdsPerCU = 163840;
-	const int cap = (DEPTH == 10 && ONEY && ONEC && !WIDE) ? VFGS_ONE10_WG_PER_CU : ((DEPTH == 8 && ONEY && ONEC && !WIDE) ? VFGS_ONE8_WG_PER_CU : 0);
+	// (rows walked in parts included: 92-95 registers, five would be resident; 16384-wide AFGS1 +2.5 % at two frames per launch, +1 % at four: profiles/r06_ab18)
+	const int cap = (DEPTH == 10 && ONEY && ONEC) ? VFGS_ONE10_WG_PER_CU : ((DEPTH == 8 && ONEY && ONEC && !WIDE) ? VFGS_ONE8_WG_PER_CU : 0);
 	if (cap <= 0) return 0;
 	const int target = (kLdsPerCU / cap) & ~2047;        // a size with which exactly `cap` workgroups are resident (well inside any allocation granule) ...
 	const int next = (kLdsPerCU / (cap + 1)) & ~2047;    // ... and one with which cap + 1 would be
