@@ -278,7 +278,7 @@ typedef struct vfgs_hip_launch_info {
 	int parts_per_row;                /* passes over the block-parameter table a row needs (1 up to 512 blocks = 8192 samples per row) */
 	int persistent_luma_workgroups;   /* 0, or the number of luma workgroups that share the launch's luma tasks (general-form luma of small pictures) */
 	int waves_per_workgroup;
-	int lds_bytes_per_workgroup;
+	int lds_bytes_per_workgroup;      /* LDS the kernel allocates: table image + block parameters (the 10-bit all-one-pattern kernels: padded to 40,960, four workgroups per CU) */
 	unsigned long long launches;      /* grain launches of this process so far */
 	char kernel[96];
 	int listed;                       /* 1: the frames' plane pointers came as a list (vfgs_hip_add_grain_frame_list_*) */

@@ -2,7 +2,7 @@
 
 The residency of the grain kernels is a measured choice: no kernel spills a vector register or uses scratch, the
 kernels with a general-form plane hold a CU at four workgroups by their 40 KB image, the 10-bit all-one-pattern kernels are held at
-four by LDS they allocate and do not use (six would fit; vfgs_kernel.hip lds_pad), the 8-bit all-one-pattern kernels fit six per CU
+four by LDS they allocate and do not use (six would fit; vfgs_layout.h lds_allocation), the 8-bit all-one-pattern kernels fit six per CU
 (79 registers, 22.8 KB).  A compiler or source change that moves one of these moves the measured numbers with it: this test reads the
 AMDGPU metadata notes of the product library (no GPU needed) and says which.
 """

@@ -130,6 +130,11 @@ def test_rows_walked_in_parts(hip, name, width):
     assert info["parts_per_row"] == (width + 15) // 16 // 512 + ((width + 15) // 16 % 512 > 0)
     assert (info["one_y"], info["one_c"]) == WIDE_FORM[name], info
     assert info["rows_per_wave"] == [1, 1]
+    # the LDS the kernel allocates (vfgs_layout.h lds_allocation): the 10-bit all-one-pattern kernels pad to four workgroups per CU
+    if depth == 10 and WIDE_FORM[name] == (1, 1):
+        assert info["lds_bytes_per_workgroup"] == 40960, info
+    else:
+        assert 15000 < info["lds_bytes_per_workgroup"] <= 40960, info
 
 
 def test_widest_picture(hip):

@@ -1544,7 +1544,7 @@ int run_device(const void* sY, const void* sU, const void* sV, void* dY, void* d
 		li.persistent_luma_workgroups = persist ? a.persist_wgs : 0;
 		li.waves_per_workgroup = vfgs::kWavesPerWG;
 		const vfgs::ImageLayout L = vfgs::layout_of(s.csubx, s.csuby, s.img_one_y, s.img_one_c, s.bs == 0);
-		li.lds_bytes_per_workgroup = L.lds_bytes + vfgs::kParamBytes;
+		li.lds_bytes_per_workgroup = vfgs::lds_allocation(s.bs != 0, s.img_one_y, s.img_one_c, wide, L.lds_bytes + vfgs::kParamBytes);     // (what the kernel allocates)
 		vfgs::describe_launch(li.kernel, sizeof li.kernel, 8 + s.bs, s.csubx, s.csuby, dg.out8, s.img_one_y, s.img_one_c, wide, persist);
 		g_last_launch_valid = true;
 	}

@@ -992,29 +992,13 @@ constexpr int rw_waves_per_simd()
 	return (DEPTH == 8 && ONEY && ONEC && !WIDE && VFGS_WG_PER_CU == 4) ? (kPk16 ? VFGS_PK_WAVES : 5) : (kWavesPerWG * VFGS_WG_PER_CU + 3) / 4;
 }
 
-// Resident workgroups per CU by LDS: the all-one-pattern kernels need 15 KB of it and few registers, so a CU would take six (10 bit) of
-// them -- 24 waves x 4 KiB of loads in flight -- and the memory system answers fewer, deeper-ringed waves better (VFGS_ONE10_WG_PER_CU in
-// vfgs_layout.h); the kernels with a general-form plane are at four by their 40 KB image anyway.
-template <int DEPTH, bool ONEY, bool ONEC, bool WIDE>
-constexpr int lds_pad(const int need)
-{
-	constexpr int kLdsPerCU = 163840;
-	// (rows walked in parts included: 92-95 registers, five would be resident; 16384-wide AFGS1 +2.5 % at two frames per launch, +1 % at four: profiles/r06_ab18)
-	const int cap = (DEPTH == 10 && ONEY && ONEC) ? VFGS_ONE10_WG_PER_CU : ((DEPTH == 8 && ONEY && ONEC && !WIDE) ? VFGS_ONE8_WG_PER_CU : 0);
-	if (cap <= 0) return 0;
-	const int target = (kLdsPerCU / cap) & ~2047;        // a size with which exactly `cap` workgroups are resident (well inside any allocation granule) ...
-	const int next = (kLdsPerCU / (cap + 1)) & ~2047;    // ... and one with which cap + 1 would be
-	return need > next ? 0 : (target < 65536 ? target : 65536) - need;
-}
-
 // in place or out of place; workgroups numbered frame -> plane -> block row -> part of the block row
 template <int DEPTH, int CSUBX, int CSUBY, bool OUT8, bool ONEY, bool ONEC, bool WIDE, bool PERSIST>
 __global__ __launch_bounds__(kWavesPerWG * 64, (rw_waves_per_simd<DEPTH, ONEY, ONEC, WIDE>())) void grain_rw_kernel(const KernelArgs a, const FrameTable ft)
 {
 	constexpr ImageLayout L = image_layout(CSUBX, CSUBY, ONEY, ONEC, DEPTH == 8);
-	// (unused LDS behind the tables holds a kernel at no more than its class's workgroups per CU: lds_pad below)
-	constexpr int PAD = lds_pad<DEPTH, ONEY, ONEC, WIDE>(L.lds_bytes + kParamBytes);
-	__shared__ __attribute__((aligned(16))) uint8_t lds[L.lds_bytes + kParamBytes + PAD];
+	// (unused LDS behind the tables holds a kernel at no more than its class's workgroups per CU: vfgs_layout.h lds_allocation)
+	__shared__ __attribute__((aligned(16))) uint8_t lds[lds_allocation(DEPTH == 10, ONEY, ONEC, WIDE, L.lds_bytes + kParamBytes)];
 
 	const int lane = threadIdx.x & 63;
 	// wave-uniform by construction; telling the compiler keeps the decoding, row offsets and buffer descriptors in SGPRs

@@ -46,7 +46,7 @@ constexpr int kBlock = 16;       // luma samples per grain block
 #ifndef VFGS_RING_NARROW10
 #define VFGS_RING_NARROW10 2  // one-pattern planes at 10 bit whose rows are one or two positions (1080p chroma): 1080p fgs_sei +2.4 % at 8, +1.1 % at 32 frames per launch, ff_test1 +0 .. 0.3 % (profiles/r06_ab8)
 #endif
-// Resident workgroups per CU of the all-one-pattern kernels, held there by unused LDS behind their tables (vfgs_kernel.hip lds_pad; 0 = as many as fit).
+// Resident workgroups per CU of the all-one-pattern kernels, held there by unused LDS behind their tables (lds_allocation below; 0 = as many as fit).
 // Their 15 KB of LDS and ~80 registers would let SIX in: 24 waves with four 1 KiB loads each in flight per CU, and the memory system answers a CU
 // that asks for less at once better (tools/walk_probe.hip depth: 20-24 KiB of loads in flight per CU stream at 0.79-0.80 of 8 TB/s, 64-96 KiB at
 // 0.73-0.75).  At 10 bit FOUR are worth +1.5 .. 4 % from 720p to 4320p (three: up to +5.7 % at 1080p / 2160p, -5 % at 720p;
@@ -87,6 +87,20 @@ constexpr int kTileBlocks = 512;
 constexpr int kParamEntries = kTileBlocks + 4;   // entry e = block e - 1; the lanes behind a row's end read up to block nblk + 2 (clamped values)
 constexpr int kParamTableBytes = (kParamEntries * 4 + 15) & ~15;
 constexpr int kParamBytes = 2 * kParamTableBytes;
+
+// LDS a grain kernel ALLOCATES: what it uses (table image + block parameters), padded where its class is held at fewer resident
+// workgroups per CU than would fit (VFGS_ONE10_WG_PER_CU / VFGS_ONE8_WG_PER_CU above): a size with which exactly that many are resident.
+// The all-one-pattern kernels at 10 bit (rows walked in parts included: 92-95 registers, five would be resident -- 16384-wide AFGS1 +2.5 % at two
+// frames per launch, +1 % at four: profiles/r06_ab18) need 15 KB and allocate 40; the kernels with a general-form plane are at four by their 40 KB image.
+constexpr int kLdsPerCU = 163840;
+constexpr int lds_allocation(const bool depth10, const bool one_y, const bool one_c, const bool wide, const int need)
+{
+	const int cap = (depth10 && one_y && one_c) ? VFGS_ONE10_WG_PER_CU : ((!depth10 && one_y && one_c && !wide) ? VFGS_ONE8_WG_PER_CU : 0);
+	if (cap <= 0) return need;
+	const int target = (kLdsPerCU / cap) & ~2047;        // exactly `cap` workgroups resident (well inside any allocation granule) ...
+	const int next = (kLdsPerCU / (cap + 1)) & ~2047;    // ... and a size with which cap + 1 would be
+	return need > next ? need : (target < 65536 ? target : 65536);
+}
 
 // Device image of everything the kernel looks up: one sub-image per plane type (luma; chroma) -- or per chroma
 // component -- and a workgroup (which works on ONE plane) copies the sub-image of its plane to LDS offset 0.
