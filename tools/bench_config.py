@@ -38,6 +38,8 @@ CONFIGS = [  # BASELINE.json configs[i]: name, w, h, depth, (subx, suby), trace,
     ("16384x2160 10-bit 4:2:0 fgs_afgs1_test1", 16384, 2160, 10, (2, 2), "fgs_afgs1_test1_10_420", "grain_rw_kernel<10,2,2,false,true,true,true,false>"),
     ("16384x2160 8-bit 4:4:4 fgs_afgs1_test1", 16384, 2160, 8, (1, 1), "fgs_afgs1_test1_8_444", "grain_rw_kernel<8,1,1,false,true,true,true,false>"),
     ("16384x2160 10-bit 4:2:0 fgs_sei", 16384, 2160, 10, (2, 2), "fgs_sei_10_420", "grain_rw_kernel<10,2,2,false,false,true,true,false>"),
+    # 16: one luma pattern over several chroma patterns at 4:2:0 (one-pattern luma, general-form chroma: 15 KB of LDS)
+    ("3840x2160 10-bit 4:2:0 fgs_sei_ff_test6", 3840, 2160, 10, (2, 2), "fgs_sei_ff_test6_10_420", "grain_rw_kernel<10,2,2,false,true,false,false,false>"),
 ]
 
 

@@ -90,12 +90,14 @@ constexpr int kParamBytes = 2 * kParamTableBytes;
 
 // LDS a grain kernel ALLOCATES: what it uses (table image + block parameters), padded where its class is held at fewer resident
 // workgroups per CU than would fit (VFGS_ONE10_WG_PER_CU / VFGS_ONE8_WG_PER_CU above): a size with which exactly that many are resident.
-// The all-one-pattern kernels at 10 bit (rows walked in parts included: 92-95 registers, five would be resident -- 16384-wide AFGS1 +2.5 % at two
+// The kernels with one-pattern luma at 10 bit (rows walked in parts included: 92-95 registers, five would be resident -- 16384-wide AFGS1 +2.5 % at two
 // frames per launch, +1 % at four: profiles/r06_ab18) need 15 KB and allocate 40; the kernels with a general-form plane are at four by their 40 KB image.
 constexpr int kLdsPerCU = 163840;
 constexpr int lds_allocation(const bool depth10, const bool one_y, const bool one_c, const bool wide, const int need)
 {
-	const int cap = (depth10 && one_y && one_c) ? VFGS_ONE10_WG_PER_CU : ((!depth10 && one_y && one_c && !wide) ? VFGS_ONE8_WG_PER_CU : 0);
+	// (10 bit: every kernel whose LUMA is one-pattern -- over general-form chroma at 4:2:0 / 4:2:2 it needs 15-23 KB and five would be resident: +0.9 .. 1.3 %,
+	// profiles/r06_ab23; over general-form chroma at 4:4:4 the 40 KB image decides anyway)
+	const int cap = (depth10 && one_y) ? VFGS_ONE10_WG_PER_CU : ((!depth10 && one_y && one_c && !wide) ? VFGS_ONE8_WG_PER_CU : 0);
 	if (cap <= 0) return need;
 	const int target = (kLdsPerCU / cap) & ~2047;        // exactly `cap` workgroups resident (well inside any allocation granule) ...
 	const int next = (kLdsPerCU / (cap + 1)) & ~2047;    // ... and a size with which cap + 1 would be
